@@ -1,0 +1,161 @@
+"""Generates tests/golden/*.npz by running the REPAIRED REFERENCE itself (imported from
+/root/reference through oracle/ref_harness.py — SURVEY.md §0.1 repairs) in the build
+container.  The reference cannot travel to the GPU box, these vectors can.
+
+Every fixture stores: the model kwargs, the synthetic-weight seed (weights are regenerated
+with fastspeech2_amd.synth.synth_state_dict — numpy PCG64, portable), the inputs and the
+reference's outputs.  Nothing of the reference's source text is stored.
+
+    python tests/golden/make_golden.py            # rewrites every fixture
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from fastspeech2_amd import synth          # noqa: E402
+from oracle import ref_harness             # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+TINY_A = dict(idim=40, odim=20, adim=64, aheads=2, positionwise_layer_type="conv1d",
+              positionwise_conv_kernel_size=9, eunits=128, dunits=128, elayers=2, dlayers=2,
+              duration_predictor_chans=64, postnet_layers=0, use_scaled_pos_enc=False)
+TINY_B = dict(idim=30, odim=16, adim=128, aheads=2, positionwise_layer_type="linear",
+              eunits=256, dunits=256, elayers=1, dlayers=1, duration_predictor_chans=128,
+              postnet_layers=0, use_scaled_pos_enc=True)
+TINY_C = dict(idim=50, odim=24, adim=192, aheads=2, positionwise_layer_type="conv1d",
+              positionwise_conv_kernel_size=3, eunits=192, dunits=320, elayers=1, dlayers=2,
+              duration_predictor_chans=96, duration_predictor_layers=3,
+              encoder_normalized_before=False, decoder_normalized_before=True,
+              encoder_concat_after=True, decoder_concat_after=False,
+              postnet_layers=0, use_scaled_pos_enc=True)
+YAML_DIMS = dict(idim=60, odim=80, adim=384, aheads=4, positionwise_layer_type="linear",
+                 eunits=1536, dunits=1536, elayers=2, dlayers=2, postnet_layers=0,
+                 use_scaled_pos_enc=True)
+BASELINE = dict(idim=80, odim=80, use_scaled_pos_enc=True, **synth.BASELINE_OVERRIDES)
+
+
+def build(cfg, seed, dur_bias, alpha=1.0):
+    kw = dict(cfg)
+    idim, odim = kw.pop("idim"), kw.pop("odim")
+    ns = ref_harness.load()
+    model = ns.FeedForwardTransformer(idim, odim, **kw)
+    sd = synth.synth_state_dict(idim, odim, seed, dur_bias=dur_bias, alpha=alpha, **kw)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    model.eval()
+    return model
+
+
+def ids_for(cfg, lengths, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return [rng.integers(1, cfg["idim"], size=L, dtype=np.int64) for L in lengths]
+
+
+def run_inference_case(name, cfg, seed, dur_bias, lengths, alpha=1.0, duration_control=1.0):
+    model = build(cfg, seed, dur_bias, alpha)
+    xs = ids_for(cfg, lengths, seed + 1)
+    arrays = {}
+    margins = []
+    for i, x in enumerate(xs):
+        xt = torch.from_numpy(x)
+        with torch.no_grad():
+            ilens = torch.LongTensor([xt.shape[0]])
+            x_masks = model._source_mask(ilens)
+            hs, _ = model.encoder.forward(xt.unsqueeze(0), x_masks)
+            va = model.variance_adaptor
+            logd = va.duration_predictor.forward(hs, None)
+            d = va.duration_predictor.inference(hs, None)
+            d_in = d.clone()
+            hs_lr = va.length_regulator.forward(hs, d_in, ilens, duration_control)
+            p = va.pitch_predictor.forward(hs_lr, None)
+            e = va.energy_predictor.forward(hs_lr, None)
+            if duration_control == 1.0:
+                mel = model.inference(xt, None)
+            else:
+                pe = va.pitch_embed.forward(p.transpose(1, 2)).transpose(1, 2)
+                ee = va.energy_embed.forward(e.transpose(1, 2)).transpose(1, 2)
+                zs, _ = model.decoder.forward(hs_lr + (ee + pe), None)
+                mel = model.feat_out(zs).view(1, -1, model.odim)[0]
+        frac = (logd.exp() - 1.0).numpy().ravel()
+        margins.append(float(np.min(np.abs(frac - np.floor(frac) - 0.5))))
+        arrays["ids_%d" % i] = x
+        arrays["mel_%d" % i] = mel.numpy().astype(np.float32)
+        arrays["dur_pred_%d" % i] = d[0].numpy().astype(np.int64)      # before LengthRegulator
+        arrays["dur_after_lr_%d" % i] = d_in[0].numpy().astype(np.int64)  # D9-visible value
+        arrays["logdur_%d" % i] = logd[0].numpy().astype(np.float32)
+        arrays["enc_out_%d" % i] = hs[0].numpy().astype(np.float32)
+        arrays["pitch_%d" % i] = p[0].numpy().astype(np.float32)
+        arrays["energy_%d" % i] = e[0].numpy().astype(np.float32)
+        arrays["frames_%d" % i] = np.array(mel.shape[0], dtype=np.int64)
+    meta = dict(name=name, cfg=cfg, seed=seed, dur_bias=dur_bias, alpha=alpha,
+                duration_control=duration_control, n=len(xs), rounding_margin=min(margins),
+                torch=torch.__version__)
+    arrays["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print("%-28s n=%d frames=%s margin=%.2e" % (name, len(xs),
+          [int(arrays["frames_%d" % i]) for i in range(len(xs))], min(margins)))
+
+
+def run_train_case(name, cfg, seed, dur_bias, B, Tp, alpha=1.0):
+    """Equal-length batch (no padding) so the reference's padded-batch arithmetic equals the
+    per-utterance semantics; loss terms read back through a reporter spy."""
+    model = build(cfg, seed, dur_bias, alpha)
+    rng = np.random.Generator(np.random.PCG64(seed + 2))
+    xs = rng.integers(1, cfg["idim"], size=(B, Tp), dtype=np.int64)
+    ds = rng.integers(0, 5, size=(B, Tp), dtype=np.int64)
+    total = int(ds[0].sum())
+    for b in range(1, B):                       # make every row sum to the same frame count
+        diff = total - int(ds[b].sum())
+        ds[b, 0] += max(diff, 0)
+        j = 0
+        while ds[b].sum() > total:
+            take = min(ds[b, j], ds[b].sum() - total)
+            ds[b, j] -= take
+            j += 1
+    assert all(int(ds[b].sum()) == total for b in range(B)) and total > 0
+    ys = rng.standard_normal((B, total, cfg["odim"]), dtype=np.float32)
+    ps = rng.standard_normal((B, total, 4), dtype=np.float32)
+    es = rng.standard_normal((B, total, 1), dtype=np.float32)
+    ilens = np.full((B,), Tp, np.int64)
+    olens = np.full((B,), total, np.int64)
+    got = {}
+
+    class Spy:
+        def report(self, dicts):
+            for d in dicts:
+                got.update(d)
+    model.reporter = Spy()
+    with torch.no_grad():
+        loss = model.forward(torch.from_numpy(xs), torch.from_numpy(ilens), torch.from_numpy(ys),
+                             torch.from_numpy(olens), torch.from_numpy(ds), torch.from_numpy(ps),
+                             torch.from_numpy(es))
+    meta = dict(name=name, cfg=cfg, seed=seed, dur_bias=dur_bias, alpha=alpha, torch=torch.__version__,
+                losses={k: float(v) for k, v in got.items()}, loss=float(loss))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), xs=xs, ilens=ilens, ys=ys, olens=olens,
+                        ds=ds, ps=ps, es=es, meta=np.array(json.dumps(meta)))
+    print("%-28s loss=%.6f %s" % (name, float(loss), {k: round(float(v), 5) for k, v in got.items()}))
+
+
+def main():
+    torch.set_num_threads(8)
+    run_inference_case("tiny_conv9_plain", TINY_A, 11, math.log(4.0), [1, 7, 23, 40])
+    run_inference_case("tiny_linear_scaled", TINY_B, 12, math.log(3.0), [2, 17, 33], alpha=0.8)
+    run_inference_case("tiny_conv3_mixed_ln", TINY_C, 13, math.log(5.0), [5, 12, 31], alpha=1.1)
+    run_inference_case("yaml_dims_2x2", YAML_DIMS, 14, math.log(4.0), [9, 26], alpha=1.0)
+    run_inference_case("d9_zero_durations", TINY_A, 11, -10.0, [6, 15])
+    run_inference_case("duration_control_0p8", TINY_A, 11, math.log(4.0), [7, 23], duration_control=0.8)
+    run_inference_case("duration_control_1p3", TINY_A, 11, math.log(4.0), [7, 23], duration_control=1.3)
+    run_inference_case("baseline_4x4", BASELINE, 1234, math.log(7.67), [120, 61])
+    run_train_case("train_tiny_conv9", TINY_A, 11, math.log(4.0), B=3, Tp=9)
+    run_train_case("train_tiny_linear", TINY_B, 12, math.log(3.0), B=2, Tp=14, alpha=0.8)
+
+
+if __name__ == "__main__":
+    main()

