@@ -1,0 +1,92 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) FastSpeech2 kernels.
+// wave = 64 lanes; MFMA tiles are 16x16 with K = 32 elements per "fragment step".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fs2 {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+
+constexpr int WAVE = 64;
+
+// ---- element <-> float ---------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---- MFMA fragment abstraction --------------------------------------------------------
+// A fragment is 8 consecutive K-elements held by one lane: lane l = (g = l >> 4, i = l & 15)
+// holds elements k = 8g .. 8g+7 of row/column i, so one fragment step covers K = 32.
+//   bf16: ONE v_mfma_f32_16x16x32_bf16 (A[i][8g+j], B[8g+j][i] — cdna guide §3).
+//   f32 : EIGHT v_mfma_f32_16x16x4_f32; MFMA j consumes element j of every lane, i.e. its
+//         k-slot g is the real k = 8g+j.  A and B use the same slot->k map, and the sum over
+//         k is order-free, so the result is the exact fp32 product (fma chain).
+// Both give C[row = 4g + r][col = i] in acc[r]  (rows from the A operand, cols from B).
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<float> { typedef f32x8 type; };
+
+__device__ __forceinline__ f32x4 mma16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(const f32x8& a, const f32x8& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_zero() {
+    typename Frag<T>::type z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (T)0.0f;
+    return z;
+}
+
+// 16-byte vector copy helpers
+struct __attribute__((aligned(16))) vec16 { uint32_t x, y, z, w; };
+
+// ---- wave reductions -------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace fs2
+
+// ---- error codes of the C ABI (include/fs2_hip.h) -----------------------------------------
+#define FS2_OK 0
+#define FS2_ERR_ARG (-1)
+#define FS2_ERR_UNSUPPORTED (-2)
+#define FS2_ERR_HIP (-3)
+
+extern "C" void fs2_set_error(const char* fmt, ...);
+
+#define FS2_CHECK_ARG(cond, ...)              \
+    do {                                      \
+        if (!(cond)) {                        \
+            fs2_set_error(__VA_ARGS__);       \
+            return FS2_ERR_ARG;               \
+        }                                     \
+    } while (0)
+
+#define FS2_CHECK_LAUNCH(name)                                              \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            fs2_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return FS2_ERR_HIP;                                             \
+        }                                                                   \
+    } while (0)

@@ -1,0 +1,480 @@
+// HBM-bound row kernels of the FastSpeech2 forward path (gfx950): embedding + positional
+// encoding, LayerNorm, tiny output heads, duration rounding, the LengthRegulator (scan + gather),
+// variance-embedding add fused with the decoder positional encoding, and packed<->padded moves.
+// All activations are packed ragged matrices [rows, channels], channel-last, fp32 residual stream
+// with an optional low-precision (bf16) copy for the MFMA kernels.
+#include "common.h"
+
+namespace fs2 {
+
+// ---------------------------------------------------------------------------------------
+// row tables: seg[m] = (start, end) of the utterance that owns row m, pos[m] = m - start
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const int* __restrict__ cu, int B, int m) {
+    // largest b with cu[b] <= m   (cu is non-decreasing, cu[0] = 0, empty segments allowed)
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= m) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void build_seg_kernel(const int* __restrict__ cu, int B, int2* __restrict__ seg,
+                                 int* __restrict__ pos, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int b = find_segment(cu, B, m);
+    seg[m] = make_int2(cu[b], cu[b + 1]);
+    if (pos) pos[m] = m - cu[b];
+}
+
+// ---------------------------------------------------------------------------------------
+// a1: Embedding(padding_idx=0) + PositionalEncoding / ScaledPositionalEncoding
+//   network/fastspeech2.py:116-120, network/encoder.py:125-128 (x*sqrt(d)+pe), :142-145 (x+alpha*pe)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_posenc_kernel(const long long* __restrict__ ids, const int* __restrict__ pos,
+                                    const float* __restrict__ emb, const float* __restrict__ pe,
+                                    float xscale, float alpha, float* __restrict__ out_f32,
+                                    T* __restrict__ out_t, int M, int d, int idim) {
+    const int dv = d >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * dv) return;
+    const int m = (int)(idx / dv), c = (int)(idx % dv) * 4;
+    long long id = ids[m];
+    id = id < 0 ? 0 : (id >= idim ? idim - 1 : id);
+    const f32x4 e = *(const f32x4*)(emb + (size_t)id * d + c);
+    const f32x4 p = *(const f32x4*)(pe + (size_t)pos[m] * d + c);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = e[r] * xscale + alpha * p[r];
+    if (out_f32) *(f32x4*)(out_f32 + (size_t)m * d + c) = v;
+    if (out_t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out_t[(size_t)m * d + c + r] = from_f32<T>(v[r]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a2: LayerNorm over channels, eps 1e-12 (network/utils.py:39-47). One wave per row,
+// two-pass statistics in registers (mean, then centred variance) in fp32.
+// ---------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ out_f32,
+                                                        T* __restrict__ out_t, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int cv = C >> 2;
+    const float* xr = x + (size_t)row * C;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            v[k] = *(const f32x4*)(xr + j * 4);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dlt = v[k][r] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            const f32x4 ww = *(const f32x4*)(w + j * 4);
+            const f32x4 bb = *(const f32x4*)(b + j * 4);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
+            if (out_f32) *(f32x4*)(out_f32 + (size_t)row * C + j * 4) = o;
+            if (out_t) {
+                T* ot = out_t + (size_t)row * C + j * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[r] = from_f32<T>(o[r]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// tiny heads: out[m, j] = x[m, :] . W[j, :] + b[j], j < NOUT <= 8, fp32 (predictor `linear`,
+// network/variance_adaptor.py:78,:115).  One wave per row.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ b, float* __restrict__ out,
+                                                     int M, int C, int NOUT) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int cv = C >> 2;
+    const float* xr = x + (size_t)row * C;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = lane; k < cv; k += 64) {
+        const f32x4 xv = *(const f32x4*)(xr + k * 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < NOUT) {
+                const f32x4 wv = *(const f32x4*)(W + (size_t)j * C + k * 4);
+                acc[j] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < NOUT) {
+            const float t = wave_sum(acc[j]);
+            if (lane == 0) out[(size_t)row * NOUT + j] = t + b[j];
+        }
+    }
+}
+
+// a8: DurationPredictor.inference rounding — clamp(round(exp(x) - 1), min=0).long()
+// (network/variance_adaptor.py:135; torch.round = round-half-to-even = rintf)
+__global__ void duration_round_kernel(const float* __restrict__ logd, int* __restrict__ dur, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float v = rintf(expf(logd[m]) - 1.0f);
+    v = v > 0.f ? v : 0.f;             // also maps NaN to 0
+    v = fminf(v, 1.0e6f);
+    dur[m] = (int)v;
+}
+
+// ---------------------------------------------------------------------------------------
+// a9: LengthRegulator (network/variance_adaptor.py:13-31).
+// plan: per utterance — optional duration_control rounding (:18-19), all-zero row -> ones
+// (D9, :28-30), inclusive scan; then utterance offsets.  One workgroup; the whole problem is
+// a few thousand integers.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lr_plan_kernel(const int* __restrict__ dur_in, const int* __restrict__ cu_phone,
+                                                      float control, int apply_control, int* __restrict__ dur_out,
+                                                      int* __restrict__ cum, int* __restrict__ olens,
+                                                      int* __restrict__ cu_frames, int B) {
+    __shared__ int sh[256];
+    __shared__ int carry_sh;
+    const int tid = threadIdx.x;
+    int frames_before = 0;
+    for (int b = 0; b < B; ++b) {
+        const int p0 = cu_phone[b], p1 = cu_phone[b + 1];
+        // pass 1: scaled durations + their sum
+        int local = 0;
+        for (int p = p0 + tid; p < p1; p += 256) {
+            int dv = dur_in[p];
+            if (apply_control) dv = (int)rintf((float)dv * control);
+            dur_out[p] = dv;
+            local += dv;
+        }
+        sh[tid] = local;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) sh[tid] += sh[tid + o];
+            __syncthreads();
+        }
+        const int total = sh[0];
+        __syncthreads();
+        const bool all_zero = (total == 0);
+        // pass 2: inclusive scan in chunks of 256 with a running carry
+        if (tid == 0) carry_sh = 0;
+        __syncthreads();
+        for (int base = p0; base < p1; base += 256) {
+            const int p = base + tid;
+            int dv = 0;
+            if (p < p1) {
+                dv = all_zero ? 1 : dur_out[p];
+                if (all_zero) dur_out[p] = 1;
+            }
+            sh[tid] = dv;
+            __syncthreads();
+            for (int o = 1; o < 256; o <<= 1) {
+                const int t = (tid >= o) ? sh[tid - o] : 0;
+                __syncthreads();
+                sh[tid] += t;
+                __syncthreads();
+            }
+            const int carry = carry_sh;
+            if (p < p1) cum[p] = carry + sh[tid];
+            __syncthreads();
+            if (tid == 255) carry_sh = carry + sh[255];
+            __syncthreads();
+        }
+        const int olen = all_zero ? (p1 - p0) : total;
+        if (tid == 0) {
+            olens[b] = olen;
+            cu_frames[b] = frames_before;
+        }
+        frames_before += olen;
+        __syncthreads();
+    }
+    if (tid == 0) cu_frames[B] = frames_before;
+}
+
+// gather: frame t of utterance b copies phone j = #{ p : cum_b[p] <= t } (zero-duration phones
+// are skipped).  One wave per output frame; the search is wave-uniform, the copy is 16 B/lane.
+template <typename T>
+__global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict__ hs, const int* __restrict__ cum,
+                                                        const int* __restrict__ cu_phone,
+                                                        const int* __restrict__ cu_frames, int B,
+                                                        float* __restrict__ out_f32, T* __restrict__ out_t,
+                                                        int2* __restrict__ frame_seg, int* __restrict__ frame_pos,
+                                                        int* __restrict__ lr_index, int Mf, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= Mf) return;
+    const int b = find_segment(cu_frames, B, row);
+    const int f0 = cu_frames[b];
+    const int t = row - f0;
+    const int p0 = cu_phone[b], p1 = cu_phone[b + 1];
+    // first phone p in [p0, p1) with cum[p] > t
+    int lo = p0, hi = p1 - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    if (lane == 0) {
+        frame_seg[row] = make_int2(f0, cu_frames[b + 1]);
+        frame_pos[row] = t;
+        lr_index[row] = lo - p0;
+    }
+    const float* src = hs + (size_t)lo * d;
+    const int dv = d >> 2;
+    for (int k = lane; k < dv; k += 64) {
+        const f32x4 v = *(const f32x4*)(src + k * 4);
+        if (out_f32) *(f32x4*)(out_f32 + (size_t)row * d + k * 4) = v;
+        if (out_t) {
+            T* o = out_t + (size_t)row * d + k * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a11 + a12 + decoder a1: hs += pitch_embed(p) + energy_embed(e)  (Conv1d kernel 1 ==
+// per-frame affine map, network/variance_adaptor.py:35-51, :203-206), then the decoder's
+// positional encoding (network/encoder.py:216-219).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void variance_add_posenc_kernel(const float* __restrict__ hs, const float* __restrict__ pitch,
+                                           const float* __restrict__ energy, const float* __restrict__ Wp,
+                                           const float* __restrict__ bp, const float* __restrict__ We,
+                                           const float* __restrict__ be, float pscale, float escale,
+                                           const float* __restrict__ pe, const int* __restrict__ pos, float xscale,
+                                           float alpha, float* __restrict__ hs_va, float* __restrict__ out_f32,
+                                           T* __restrict__ out_t, int M, int d, int pdim, int edim) {
+    const int dv = d >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * dv) return;
+    const int m = (int)(idx / dv), c = (int)(idx % dv) * 4;
+    const f32x4 h = *(const f32x4*)(hs + (size_t)m * d + c);
+    const f32x4 pp = *(const f32x4*)(pe + (size_t)pos[m] * d + c);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float pemb = bp[c + r];
+        for (int j = 0; j < pdim; ++j) pemb += Wp[(c + r) * pdim + j] * (pitch[(size_t)m * pdim + j] * pscale);
+        float eemb = be[c + r];
+        for (int j = 0; j < edim; ++j) eemb += We[(c + r) * edim + j] * (energy[(size_t)m * edim + j] * escale);
+        const float x = h[r] + (eemb + pemb);
+        if (hs_va) hs_va[(size_t)m * d + c + r] = x;
+        v[r] = x * xscale + alpha * pp[r];
+    }
+    if (out_f32) *(f32x4*)(out_f32 + (size_t)m * d + c) = v;
+    if (out_t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out_t[(size_t)m * d + c + r] = from_f32<T>(v[r]);
+    }
+}
+
+// packed [M, C] -> padded [B, Tmax, C] (zeros beyond each utterance's length)
+__global__ void unpack_padded_kernel(const float* __restrict__ src, const int* __restrict__ cu, float* __restrict__ dst,
+                                     int B, int Tmax, int C) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)B * Tmax * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const long long bt = idx / C;
+    const int t = (int)(bt % Tmax), b = (int)(bt / Tmax);
+    const int len = cu[b + 1] - cu[b];
+    dst[idx] = t < len ? src[(size_t)(cu[b] + t) * C + c] : 0.f;
+}
+
+// padded [B, Tmax, C] -> packed [M, C]
+__global__ void pack_padded_kernel(const float* __restrict__ src, const int2* __restrict__ seg, const int* __restrict__ cu,
+                                   float* __restrict__ dst, int B, int Tmax, int C, int M) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * C) return;
+    const int c = (int)(idx % C);
+    const int m = (int)(idx / C);
+    const int b = find_segment(cu, B, m);
+    dst[idx] = src[((size_t)b * Tmax + (m - cu[b])) * C + c];
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) dst[idx] = from_f32<T>(src[idx]);
+}
+
+}  // namespace fs2
+
+using namespace fs2;
+
+static inline int blocks_for(long long n, int per) { return (int)((n + per - 1) / per); }
+
+extern "C" int fs2_build_seg(const int* cu, int B, int* seg, int* pos, int M, hipStream_t stream) {
+    FS2_CHECK_ARG(cu && seg && B > 0 && M >= 0, "fs2_build_seg: bad args");
+    if (M == 0) return FS2_OK;
+    hipLaunchKernelGGL(build_seg_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, stream, cu, B, (int2*)seg, pos, M);
+    FS2_CHECK_LAUNCH("fs2_build_seg");
+    return FS2_OK;
+}
+
+extern "C" int fs2_embed_posenc(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
+                                float alpha, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
+                                hipStream_t stream) {
+    FS2_CHECK_ARG(ids && pos && emb && pe && (out_f32 || out_t), "fs2_embed_posenc: null pointer");
+    FS2_CHECK_ARG(d > 0 && d % 4 == 0 && idim > 0 && M >= 0, "fs2_embed_posenc: d=%d must be a multiple of 4", d);
+    if (M == 0) return FS2_OK;
+    const long long n = (long long)M * (d / 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(embed_posenc_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, ids, pos, emb, pe,
+                           xscale, alpha, out_f32, (bf16_t*)out_t, M, d, idim);
+    else
+        hipLaunchKernelGGL(embed_posenc_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, ids, pos, emb, pe,
+                           xscale, alpha, out_f32, (float*)out_t, M, d, idim);
+    FS2_CHECK_LAUNCH("fs2_embed_posenc");
+    return FS2_OK;
+}
+
+extern "C" int fs2_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_t, int M, int C,
+                             float eps, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(x && w && b && (out_f32 || out_t), "fs2_layernorm: null pointer");
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "fs2_layernorm: C=%d unsupported (multiple of 4, <= %d)", C,
+                  256 * LN_MAXV);
+    if (M <= 0) return FS2_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, out_f32,
+                           (bf16_t*)out_t, M, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, out_f32,
+                           (float*)out_t, M, C, eps);
+    FS2_CHECK_LAUNCH("fs2_layernorm");
+    return FS2_OK;
+}
+
+extern "C" int fs2_rowdot(const float* x, const float* W, const float* b, float* out, int M, int C, int nout,
+                          hipStream_t stream) {
+    FS2_CHECK_ARG(x && W && b && out, "fs2_rowdot: null pointer");
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && nout >= 1 && nout <= 8, "fs2_rowdot: C=%d nout=%d unsupported", C, nout);
+    if (M <= 0) return FS2_OK;
+    hipLaunchKernelGGL(rowdot_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, W, b, out, M, C, nout);
+    FS2_CHECK_LAUNCH("fs2_rowdot");
+    return FS2_OK;
+}
+
+extern "C" int fs2_duration_round(const float* logd, int* dur, int M, hipStream_t stream) {
+    FS2_CHECK_ARG(logd && dur, "fs2_duration_round: null pointer");
+    if (M <= 0) return FS2_OK;
+    hipLaunchKernelGGL(duration_round_kernel, dim3(blocks_for(M, 256)), dim3(256), 0, stream, logd, dur, M);
+    FS2_CHECK_LAUNCH("fs2_duration_round");
+    return FS2_OK;
+}
+
+extern "C" int fs2_lr_plan(const int* dur_in, const int* cu_phone, float control, int* dur_out, int* cum, int* olens,
+                           int* cu_frames, int B, hipStream_t stream) {
+    FS2_CHECK_ARG(dur_in && cu_phone && dur_out && cum && olens && cu_frames && B > 0, "fs2_lr_plan: bad args");
+    hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, stream, dur_in, cu_phone, control,
+                       control != 1.0f ? 1 : 0, dur_out, cum, olens, cu_frames, B);
+    FS2_CHECK_LAUNCH("fs2_lr_plan");
+    return FS2_OK;
+}
+
+extern "C" int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phone, const int* cu_frames, int B,
+                             float* out_f32, void* out_t, int* frame_seg, int* frame_pos, int* lr_index, int Mf, int d,
+                             int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(hs && cum && cu_phone && cu_frames && frame_seg && frame_pos && lr_index && (out_f32 || out_t),
+                  "fs2_lr_gather: null pointer");
+    FS2_CHECK_ARG(B > 0 && d > 0 && d % 4 == 0, "fs2_lr_gather: bad dims");
+    if (Mf <= 0) return FS2_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(lr_gather_kernel<bf16_t>, dim3(blocks_for(Mf, 4)), dim3(256), 0, stream, hs, cum, cu_phone,
+                           cu_frames, B, out_f32, (bf16_t*)out_t, (int2*)frame_seg, frame_pos, lr_index, Mf, d);
+    else
+        hipLaunchKernelGGL(lr_gather_kernel<float>, dim3(blocks_for(Mf, 4)), dim3(256), 0, stream, hs, cum, cu_phone,
+                           cu_frames, B, out_f32, (float*)out_t, (int2*)frame_seg, frame_pos, lr_index, Mf, d);
+    FS2_CHECK_LAUNCH("fs2_lr_gather");
+    return FS2_OK;
+}
+
+extern "C" int fs2_variance_add_posenc(const float* hs, const float* pitch, const float* energy, const float* Wp,
+                                       const float* bp, const float* We, const float* be, float pscale, float escale,
+                                       const float* pe, const int* pos, float xscale, float alpha, float* hs_va,
+                                       float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
+                                       hipStream_t stream) {
+    FS2_CHECK_ARG(hs && pitch && energy && Wp && bp && We && be && pe && pos && (out_f32 || out_t),
+                  "fs2_variance_add_posenc: null pointer");
+    FS2_CHECK_ARG(d > 0 && d % 4 == 0 && pdim >= 1 && edim >= 1, "fs2_variance_add_posenc: bad dims");
+    if (M <= 0) return FS2_OK;
+    const long long n = (long long)M * (d / 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(variance_add_posenc_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
+                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, hs_va, out_f32,
+                           (bf16_t*)out_t, M, d, pdim, edim);
+    else
+        hipLaunchKernelGGL(variance_add_posenc_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
+                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, hs_va, out_f32,
+                           (float*)out_t, M, d, pdim, edim);
+    FS2_CHECK_LAUNCH("fs2_variance_add_posenc");
+    return FS2_OK;
+}
+
+extern "C" int fs2_unpack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C,
+                                 hipStream_t stream) {
+    FS2_CHECK_ARG(src && cu && dst && B > 0 && Tmax >= 0 && C > 0, "fs2_unpack_padded: bad args");
+    const long long n = (long long)B * Tmax * C;
+    if (n == 0) return FS2_OK;
+    hipLaunchKernelGGL(unpack_padded_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, cu, dst, B, Tmax, C);
+    FS2_CHECK_LAUNCH("fs2_unpack_padded");
+    return FS2_OK;
+}
+
+extern "C" int fs2_pack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C, int M,
+                               hipStream_t stream) {
+    FS2_CHECK_ARG(src && cu && dst && B > 0 && C > 0, "fs2_pack_padded: bad args");
+    const long long n = (long long)M * C;
+    if (n <= 0) return FS2_OK;
+    hipLaunchKernelGGL(pack_padded_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, (const int2*)nullptr, cu,
+                       dst, B, Tmax, C, M);
+    FS2_CHECK_LAUNCH("fs2_pack_padded");
+    return FS2_OK;
+}
+
+extern "C" int fs2_cast(const float* src, void* dst, long long n, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(src && dst && n >= 0, "fs2_cast: bad args");
+    if (n == 0) return FS2_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, (float*)dst, n);
+    FS2_CHECK_LAUNCH("fs2_cast");
+    return FS2_OK;
+}

@@ -1,0 +1,333 @@
+"""Host-side launch schedule of the FastSpeech2 forward path on the gfx950 kernels.
+
+`Engine` packs a reference-layout state_dict once (conv weights -> [tap][Cout][Cin], q/k/v
+projections fused into one [3d, d] matrix, optional bf16 copies) and then runs the forward as a
+sequence of C-ABI launches (include/fs2_hip.h) on torch's current HIP stream.  Activations are
+packed ragged matrices; torch is used only for device memory and streams.
+
+Schedule follows network/fastspeech2.py:187-230 (`_forward`), network/encoder.py:168-189, :248-254
+and network/variance_adaptor.py:178-207 with the repair set of SURVEY.md §0.1.
+"""
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip
+from .hip import F32, BF16, call, ptr, stream
+
+LN_EPS = 1e-12  # network/utils.py:41
+
+
+def posenc_table(T: int, d: int) -> torch.Tensor:
+    """Positional table with the reference's fp32 recipe (network/encoder.py:116-121), built on
+    the host with the same torch CPU ops so the table is bit-identical to the reference's."""
+    pe = torch.zeros(T, d)
+    position = torch.arange(0, T, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+class _Stack:
+    """Packed weights of one FFT stack (encoder or decoder)."""
+
+    def __init__(self, sd, prefix, n_layers, pre_ln, concat_after, ff_type, dev, code):
+        tdt = hip.TORCH_DTYPE[code]
+        self.pre_ln, self.concat_after, self.code = pre_ln, concat_after, code
+        f32 = lambda k: sd[prefix + k].detach().to(dev, torch.float32).contiguous()
+        self.layers = []
+        for i in range(n_layers):
+            p = "encoders.%d." % i
+            L = {}
+            wq, wk, wv = (f32(p + "self_atten.linear_%s.weight" % n) for n in "qkv")
+            L["wqkv"] = torch.cat([wq, wk, wv], 0).to(tdt).contiguous()
+            L["bqkv"] = torch.cat([f32(p + "self_atten.linear_%s.bias" % n) for n in "qkv"], 0).contiguous()
+            L["wo"] = f32(p + "self_atten.linear_out.weight").to(tdt).contiguous()
+            L["bo"] = f32(p + "self_atten.linear_out.bias")
+            w1, w2 = f32(p + "feed_forward.w1.weight"), f32(p + "feed_forward.w2.weight")
+            if ff_type == "conv1d":
+                L["taps"] = w1.shape[-1]
+                w1, w2 = w1.permute(2, 0, 1), w2.permute(2, 0, 1)
+            else:
+                L["taps"] = 1
+            L["w1"], L["w2"] = w1.to(tdt).contiguous(), w2.to(tdt).contiguous()
+            L["b1"], L["b2"] = f32(p + "feed_forward.w1.bias"), f32(p + "feed_forward.w2.bias")
+            L["units"] = L["b1"].shape[0]
+            for n in ("norm1", "norm2"):
+                L[n + "_w"], L[n + "_b"] = f32(p + n + ".weight"), f32(p + n + ".bias")
+            if concat_after:
+                wc = f32(p + "concat_linear.weight")
+                d = wc.shape[0]
+                L["wc_x"] = wc[:, :d].to(tdt).contiguous()
+                L["wc_a"] = wc[:, d:].to(tdt).contiguous()
+                L["bc"] = f32(p + "concat_linear.bias")
+            self.layers.append(L)
+        if pre_ln:
+            self.after_w, self.after_b = f32("after_norm.weight"), f32("after_norm.bias")
+
+
+class _Predictor:
+    def __init__(self, sd, prefix, dev, code):
+        tdt = hip.TORCH_DTYPE[code]
+        self.code = code
+        self.convs = []
+        j = 0
+        while "%sconv.%d.0.conv.weight" % (prefix, j) in sd:
+            w = sd["%sconv.%d.0.conv.weight" % (prefix, j)].detach().to(dev, torch.float32)
+            bkey = "%sconv.%d.0.conv.bias" % (prefix, j)
+            b = sd[bkey].detach().to(dev, torch.float32).contiguous() if bkey in sd else None
+            self.convs.append(dict(
+                w=w.permute(2, 0, 1).to(tdt).contiguous(), b=b, taps=w.shape[-1], chans=w.shape[0],
+                ln_w=sd["%sconv.%d.2.weight" % (prefix, j)].detach().to(dev, torch.float32).contiguous(),
+                ln_b=sd["%sconv.%d.2.bias" % (prefix, j)].detach().to(dev, torch.float32).contiguous()))
+            j += 1
+        self.lin_w = sd[prefix + "linear.weight"].detach().to(dev, torch.float32).contiguous()
+        self.lin_b = sd[prefix + "linear.bias"].detach().to(dev, torch.float32).contiguous()
+        self.nout = self.lin_w.shape[0]
+
+
+class Engine:
+    """dtype: 'fp32' (f32 MFMA everywhere) or 'bf16' (bf16 MFMA operands, fp32 accumulate /
+    statistics / residual).  encoder_dtype lets the phone-level half (encoder + duration
+    predictor, which decides the integer durations) run in fp32 while the frame-level half runs
+    in bf16."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, dtype: str = "fp32",
+                 encoder_dtype: Optional[str] = None, device=None):
+        self.dev = torch.device(device) if device is not None else hip.require_gpu()
+        hip.load()
+        self.cfg = cfg
+        self.dec_code = hip.DTYPE_CODE[dtype]
+        self.enc_code = hip.DTYPE_CODE[encoder_dtype or dtype]
+        self.dtype, self.encoder_dtype = dtype, (encoder_dtype or dtype)
+        d = cfg["adim"]
+        self.d, self.h = d, cfg["aheads"]
+        if d % self.h != 0:
+            raise AssertionError("n_feat % n_head != 0")          # network/encoder.py:53
+        self.dk = d // self.h
+        if self.dk not in (32, 64, 96, 128):
+            raise NotImplementedError("head dim %d: the attention kernel supports 32/64/96/128" % self.dk)
+        if cfg["positionwise_layer_type"] not in ("linear", "conv1d"):
+            raise NotImplementedError("not implemented")          # network/encoder.py:232
+        if cfg["postnet_layers"] != 0:
+            raise NotImplementedError("PostNet is defective in the reference (SURVEY.md D7); "
+                                      "use postnet_layers=0")
+        if cfg["reduction_factor"] != 1:
+            raise NotImplementedError("reduction_factor != 1")
+        sd, dev = state_dict, self.dev
+        self.scaled = cfg["use_scaled_pos_enc"]
+        ff = cfg["positionwise_layer_type"]
+        self.enc = _Stack(sd, "encoder.", cfg["elayers"], cfg["encoder_normalized_before"],
+                          cfg["encoder_concat_after"], ff, dev, self.enc_code)
+        self.dec = _Stack(sd, "decoder.", cfg["dlayers"], cfg["decoder_normalized_before"],
+                          cfg["decoder_concat_after"], ff, dev, self.dec_code)
+        g = lambda k: sd[k].detach().to(dev, torch.float32).contiguous()
+        self.emb = g("encoder.embed.0.weight")
+        self.idim = self.emb.shape[0]
+        if self.scaled:
+            self.enc_alpha = float(sd["encoder.embed.1.alpha"])
+            self.dec_alpha = float(sd["decoder.embed.0.alpha"])
+            self.enc_xscale = self.dec_xscale = 1.0
+        else:
+            self.enc_alpha = self.dec_alpha = 1.0
+            self.enc_xscale = self.dec_xscale = math.sqrt(d)
+        va = "variance_adaptor."
+        self.dur_pred = _Predictor(sd, va + "duration_predictor.", dev, self.enc_code)
+        self.pitch_pred = _Predictor(sd, va + "pitch_predictor.", dev, self.dec_code)
+        self.energy_pred = _Predictor(sd, va + "energy_predictor.", dev, self.dec_code)
+        wp, we = g(va + "pitch_embed.conv.conv.weight"), g(va + "energy_embed.conv.conv.weight")
+        if wp.shape[-1] != 1 or we.shape[-1] != 1:
+            raise NotImplementedError("pitch/energy embed kernel size must be 1")
+        self.wp, self.bp = wp[:, :, 0].contiguous(), g(va + "pitch_embed.conv.conv.bias")
+        self.we, self.be = we[:, :, 0].contiguous(), g(va + "energy_embed.conv.conv.bias")
+        self.pdim, self.edim = self.wp.shape[1], self.we.shape[1]
+        self.w_out = g("feat_out.weight").to(hip.TORCH_DTYPE[self.dec_code]).contiguous()
+        self.b_out = g("feat_out.bias")
+        self.odim = self.w_out.shape[0]
+        self._pe = None
+        self.profile = None     # optional list collecting (tag, start_event, end_event)
+
+    # ------------------------------------------------------------------ helpers
+    def _pe_table(self, T: int) -> torch.Tensor:
+        if self._pe is None or self._pe.shape[0] < T:
+            n = max(T, 1024)
+            n = 1 << (n - 1).bit_length()
+            self._pe = posenc_table(n, self.d).to(self.dev)
+        return self._pe
+
+    def _empty(self, shape, code=None, dtype=None):
+        return torch.empty(shape, device=self.dev, dtype=dtype or hip.TORCH_DTYPE[code])
+
+    def _gemm(self, x, w, bias, M, N, Cin, taps, code, seg=None, res=None, relu=False, out_f32=False, tag=None):
+        out = self._empty((M, N), dtype=torch.float32 if out_f32 else hip.TORCH_DTYPE[code])
+        prof = self.profile is not None and tag is not None
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps,
+             Cin, N, N, int(relu), int(out_f32), code, stream())
+        if prof:
+            e1.record()
+            self.profile.append((tag, M, N, Cin * taps, e0, e1))
+        return out
+
+    def _ln(self, x, w, b, M, C, code, want_f32, want_t):
+        of = self._empty((M, C), dtype=torch.float32) if (want_f32 or (want_t and code == F32)) else None
+        ot = self._empty((M, C), code) if (want_t and code != F32) else None
+        call("fs2_layernorm", ptr(x), ptr(w), ptr(b), ptr(of), ptr(ot), M, C, LN_EPS, code, stream())
+        return of, (of if code == F32 else ot)
+
+    # ------------------------------------------------------------------ FFT stack
+    def _run_stack(self, st: _Stack, x32, xt, seg, cu_dev, B, max_len, M, attn_dump=None, lens=None):
+        d, code = self.d, st.code
+        for li, L in enumerate(st.layers):
+            # ---- self-attention sub-layer (network/encoder.py:171-180)
+            a_t = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, False, True)[1] if st.pre_ln else xt
+            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code)
+            if attn_dump is not None:
+                attn_dump.append(self._dump_attention(qkv, lens, code))
+            ctx = self._empty((M, d), code)
+            call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, code,
+                 stream())
+            if st.concat_after:
+                att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
+                y = self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, res=x32, out_f32=True)
+                y = self._gemm(att, L["wc_a"], None, M, d, d, 1, code, res=y, out_f32=True)
+            else:
+                y = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, res=x32, out_f32=True)
+            if st.pre_ln:
+                x32 = y
+            else:
+                x32, xt = self._ln(y, L["norm1_w"], L["norm1_b"], M, d, code, True, True)
+            # ---- position-wise feed-forward sub-layer (:182-187)
+            f_t = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, False, True)[1] if st.pre_ln else xt
+            taps, U = L["taps"], L["units"]
+            sg = seg if taps > 1 else None
+            hdn = self._gemm(f_t, L["w1"], L["b1"], M, U, d, taps, code, seg=sg, relu=True, tag="ffn1")
+            y = self._gemm(hdn, L["w2"], L["b2"], M, d, U, taps, code, seg=sg, res=x32, out_f32=True, tag="ffn2")
+            if st.pre_ln:
+                x32 = y
+            else:
+                x32, xt = self._ln(y, L["norm2_w"], L["norm2_b"], M, d, code, True, True)
+        if st.pre_ln:
+            x32, xt = self._ln(x32, st.after_w, st.after_b, M, d, code, True, True)
+        return x32, xt
+
+    def _dump_attention(self, qkv, lens, code):
+        outs, r0 = [], 0
+        for L in lens:
+            a = self._empty((self.h, L, L), dtype=torch.float32)
+            call("fs2_attention_dump", ptr(qkv), ptr(a), r0, L, self.h, self.dk, 3 * self.d, code, stream())
+            outs.append(a)
+            r0 += L
+        return outs
+
+    def _predict(self, pr: _Predictor, x_t, seg, M, cin):
+        cur, code = x_t, pr.code
+        n = len(pr.convs)
+        y32 = None
+        for j, c in enumerate(pr.convs):
+            y = self._gemm(cur, c["w"], c["b"], M, c["chans"], cin, c["taps"], code,
+                           seg=seg if c["taps"] > 1 else None, relu=True, out_f32=True)
+            last = j == n - 1
+            y32, cur = self._ln(y, c["ln_w"], c["ln_b"], M, c["chans"], code, last, not last)
+            cin = c["chans"]
+        out = self._empty((M, pr.nout), dtype=torch.float32)
+        call("fs2_rowdot", ptr(y32), ptr(pr.lin_w), ptr(pr.lin_b), ptr(out), M, cin, pr.nout, stream())
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, ids: torch.Tensor, ilens: Sequence[int], duration_control: float = 1.0,
+                ds: Optional[torch.Tensor] = None, ps: Optional[torch.Tensor] = None,
+                es: Optional[torch.Tensor] = None, pitch_control: float = 1.0, energy_control: float = 1.0,
+                want_attention: bool = False) -> Dict[str, object]:
+        """ids: packed int64 phone ids [sum(ilens)] on the device.  ds/ps/es: optional packed
+        overrides (teacher forcing): durations int32 [Mp], pitch fp32 [Mf,4], energy fp32 [Mf,1].
+        Returns packed outputs; `olens` is a host list (one device->host read of B+1 integers is the
+        only synchronisation of the forward)."""
+        dev, d = self.dev, self.d
+        B = len(ilens)
+        ilens = [int(v) for v in ilens]
+        Mp = int(sum(ilens))
+        assert ids.numel() == Mp and ids.dtype == torch.int64 and ids.device.type == "cuda"
+        cu_p = np.zeros(B + 1, np.int32)
+        cu_p[1:] = np.cumsum(ilens)
+        cu_phone = torch.from_numpy(cu_p).to(dev, non_blocking=True)
+        max_il = max(ilens) if B else 0
+        pe = self._pe_table(max(max_il, 1))
+        seg_p = self._empty((max(Mp, 1), 2), dtype=torch.int32)
+        pos_p = self._empty((max(Mp, 1),), dtype=torch.int32)
+        call("fs2_build_seg", ptr(cu_phone), B, ptr(seg_p), ptr(pos_p), Mp, stream())
+
+        ec = self.enc_code
+        enc_post = not self.enc.pre_ln
+        x32 = self._empty((Mp, d), dtype=torch.float32)
+        xt = self._empty((Mp, d), ec) if (enc_post and ec != F32) else None
+        call("fs2_embed_posenc", ptr(ids), ptr(pos_p), ptr(self.emb), ptr(pe), self.enc_xscale, self.enc_alpha,
+             ptr(x32), ptr(xt), Mp, d, self.idim, ec, stream())
+        if ec == F32:
+            xt = x32
+        enc_att = [] if want_attention else None
+        hs32, hst = self._run_stack(self.enc, x32, xt, seg_p, cu_phone, B, max_il, Mp, enc_att, ilens)
+
+        # ---- variance adaptor (network/variance_adaptor.py:195-207 with D6)
+        logd = self._predict(self.dur_pred, hst, seg_p, Mp, d).view(-1)
+        dur_pred = self._empty((max(Mp, 1),), dtype=torch.int32)
+        call("fs2_duration_round", ptr(logd), ptr(dur_pred), Mp, stream())
+        dur_in = dur_pred if ds is None else ds.to(dev, torch.int32).contiguous()
+        dur_used = self._empty((max(Mp, 1),), dtype=torch.int32)
+        cum = self._empty((max(Mp, 1),), dtype=torch.int32)
+        olens_dev = self._empty((B,), dtype=torch.int32)
+        cu_frames = self._empty((B + 1,), dtype=torch.int32)
+        call("fs2_lr_plan", ptr(dur_in), ptr(cu_phone), float(duration_control), ptr(dur_used), ptr(cum),
+             ptr(olens_dev), ptr(cu_frames), B, stream())
+        cu_f = cu_frames.cpu().numpy()                      # the one host sync
+        olens = np.diff(cu_f).astype(np.int64).tolist()
+        Mf = int(cu_f[-1])
+        max_ol = max(olens) if B else 0
+
+        dc = self.dec_code
+        hs_lr32 = self._empty((Mf, d), dtype=torch.float32)
+        hs_lrt = self._empty((Mf, d), dc) if dc != F32 else None
+        seg_f = self._empty((max(Mf, 1), 2), dtype=torch.int32)
+        pos_f = self._empty((max(Mf, 1),), dtype=torch.int32)
+        lr_index = self._empty((max(Mf, 1),), dtype=torch.int32)
+        call("fs2_lr_gather", ptr(hs32), ptr(cum), ptr(cu_phone), ptr(cu_frames), B, ptr(hs_lr32), ptr(hs_lrt),
+             ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
+        if dc == F32:
+            hs_lrt = hs_lr32
+        pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d)
+        energy = self._predict(self.energy_pred, hs_lrt, seg_f, Mf, d)
+        p_in = pitch if ps is None else ps.to(dev, torch.float32).contiguous()
+        e_in = energy if es is None else es.to(dev, torch.float32).contiguous()
+        pscale = float(pitch_control) if ps is None else 1.0
+        escale = float(energy_control) if es is None else 1.0
+
+        pe = self._pe_table(max(max_ol, 1))
+        dec_post = not self.dec.pre_ln
+        y32 = self._empty((Mf, d), dtype=torch.float32)
+        yt = self._empty((Mf, d), dc) if (dec_post and dc != F32) else None
+        call("fs2_variance_add_posenc", ptr(hs_lr32), ptr(p_in), ptr(e_in), ptr(self.wp), ptr(self.bp), ptr(self.we),
+             ptr(self.be), pscale, escale, ptr(pe), ptr(pos_f), self.dec_xscale, self.dec_alpha, None, ptr(y32),
+             ptr(yt), Mf, d, self.pdim, self.edim, dc, stream())
+        if dc == F32:
+            yt = y32
+        dec_att = [] if want_attention else None
+        z32, zt = self._run_stack(self.dec, y32, yt, seg_f, cu_frames, B, max_ol, Mf, dec_att, olens)
+        mel = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True)
+        out = dict(mel=mel, olens=olens, cu_frames=cu_frames, cu_phone=cu_phone, durations=dur_used[:Mp],
+                   durations_pred=dur_pred[:Mp], log_durations=logd, pitch=pitch, energy=energy,
+                   lr_index=lr_index[:Mf], enc_out=hs32, frames=Mf)
+        if want_attention:
+            out["enc_attention"], out["dec_attention"] = enc_att, dec_att
+        return out
+
+    def unpack(self, packed: torch.Tensor, cu: torch.Tensor, B: int, Tmax: int) -> torch.Tensor:
+        """packed [M, C] fp32 -> zero-padded [B, Tmax, C] (pad_list, network/utils.py:50-56)."""
+        C = packed.shape[1]
+        out = self._empty((B, Tmax, C), dtype=torch.float32)
+        call("fs2_unpack_padded", ptr(packed), ptr(cu), ptr(out), B, Tmax, C, stream())
+        return out

@@ -1,0 +1,92 @@
+"""ctypes binding of libfs2_gfx950.so (C ABI: include/fs2_hip.h).
+
+The product path has no CPU fallback: if the library is missing, or no gfx950 device is present
+when a kernel is requested, this module raises — it never routes around the HIP kernels.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+
+import torch
+
+from . import build as _build
+
+F32, BF16 = 0, 1
+DTYPE_CODE = {"fp32": F32, "bf16": BF16}
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> argtypes (all return int); mirrors include/fs2_hip.h
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
+_SIGNATURES = {
+    "fs2_build_seg": [_P, _I, _P, _P, _I, _P],
+    "fs2_embed_posenc": [_P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "fs2_conv_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_attention_dump": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "fs2_duration_round": [_P, _P, _I, _P],
+    "fs2_lr_plan": [_P, _P, _F, _P, _P, _P, _P, _I, _P],
+    "fs2_lr_gather": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "fs2_variance_add_posenc": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _F, _F, _P, _P, _P,
+                                _I, _I, _I, _I, _I, _P],
+    "fs2_unpack_padded": [_P, _P, _P, _I, _I, _I, _P],
+    "fs2_pack_padded": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_cast": [_P, _P, _L, _I, _P],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ["fs2_last_error", "fs2_abi_version", "fs2_device_arch"])
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Loads the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.isfile(path):
+        raise HipError("HIP extension %s is missing: run `python -m fastspeech2_amd.build` "
+                       "(there is no CPU fallback)" % path)
+    lib = ctypes.CDLL(path)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.fs2_last_error.restype = c_char_p
+    lib.fs2_abi_version.restype = c_int
+    lib.fs2_device_arch.argtypes = [c_char_p, c_int]
+    _lib = lib
+    return lib
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise HipError("no HIP device visible: the FastSpeech2 forward path runs only on the "
+                       "gfx950 kernels of libfs2_gfx950.so (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise HipError("%s failed (%d): %s" % (name, rc, load().fs2_last_error().decode()))

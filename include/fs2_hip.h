@@ -1,0 +1,123 @@
+/* libfs2_gfx950.so — C ABI of the MI355X (gfx950) FastSpeech2 forward-path kernels.
+ *
+ * The reference (francissfy/fastspeech2) is pure Python/PyTorch and has no FFI; each entry
+ * point below replaces the stock-ATen op sequence of the reference lines cited, and is what a
+ * ctypes binding in the reference's `network/` modules would call.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 on error (FS2_ERR_*); `fs2_last_error()` gives the
+ *    message of the calling thread's last failure.
+ *  - all pointers are DEVICE pointers (hipMalloc'ed / torch CUDA tensors), 16-byte aligned;
+ *    nothing is allocated, freed or synchronised inside; launches go to `stream`.
+ *  - activations are PACKED ragged matrices [rows, channels] (channel-last, no padding between
+ *    utterances); `cu` arrays hold B+1 int32 row offsets; `seg` tables hold, per row, the int32
+ *    pair (start, end) of its utterance.
+ *  - dtype: FS2_F32 (0) or FS2_BF16 (1) selects the operand type "T" of the MFMA kernels
+ *    (accumulation, LayerNorm / softmax statistics and the residual stream are always fp32).
+ */
+#ifndef FS2_HIP_H
+#define FS2_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS2_F32 0
+#define FS2_BF16 1
+
+#define FS2_OK 0
+#define FS2_ERR_ARG (-1)
+#define FS2_ERR_UNSUPPORTED (-2)
+#define FS2_ERR_HIP (-3)
+
+const char* fs2_last_error(void);
+int fs2_abi_version(void);
+int fs2_device_arch(char* buf, int n);
+
+/* seg[m] = (cu[b], cu[b+1]) and pos[m] = m - cu[b] for the utterance b owning row m.
+ * Replaces make_non_pad_mask/_source_mask (network/utils.py:59-86, network/fastspeech2.py:174-176):
+ * kernels consume row ranges instead of (B,T,T) boolean masks. pos may be NULL. */
+int fs2_build_seg(const int* cu, int B, int* seg /*[M][2]*/, int* pos /*[M]*/, int M, hipStream_t stream);
+
+/* out[m,:] = emb[ids[m],:] * xscale + alpha * pe[pos[m],:]
+ * nn.Embedding(padding_idx=0) + PositionalEncoding (xscale=sqrt(d), alpha=1) or
+ * ScaledPositionalEncoding (xscale=1): network/fastspeech2.py:116-120, network/encoder.py:125-128, :142-145.
+ * out_f32 / out_t: either may be NULL. */
+int fs2_embed_posenc(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
+                     float alpha, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
+                     hipStream_t stream);
+
+/* LayerNorm over channels, eps as given (reference: 1e-12), network/utils.py:39-47.
+ * x fp32 [M,C]; writes fp32 and/or T copies. C % 4 == 0, C <= 1024. */
+int fs2_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_t, int M, int C,
+                  float eps, int dtype, hipStream_t stream);
+
+/* Conv1d over time ("same" zero padding inside each utterance) or Linear (taps == 1) as an MFMA
+ * implicit GEMM:  out = [relu](sum_tap X[m+tap-pad,:] . W[tap]^T + bias) [+ res]
+ * X [M,ldx] T; W packed [taps][N][Cin] T; bias fp32 [N] or NULL; res fp32 [M,ldr] or NULL;
+ * out [M,ldo] fp32 (out_f32=1) or T.  seg is required when taps > 1.
+ * Replaces nn.Conv1d in MultiLayeredConv1d (network/encoder.py:16-30) and ConvNorm
+ * (network/utils.py:22-36), and nn.Linear in PositionwiseFeedForward / MultiHeadedAttention /
+ * feat_out (network/encoder.py:39-44, :57-60, :89; network/fastspeech2.py:158-159, :219). */
+int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out, const int* seg,
+                  int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int out_f32, int dtype,
+                  hipStream_t stream);
+
+/* Fused varlen multi-head self-attention (scores, softmax, P.V) over packed qkv [M, ld] T laid out
+ * q | k | v with each part [n_heads][dk]; ctx [M, ldo] T.  dk in {32, 64, 96, 128}.
+ * Replaces MultiHeadedAttention.forward between the projections (network/encoder.py:73-88). */
+int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
+                  int ldo, int dtype, hipStream_t stream);
+
+/* Debug: materialise softmax(QK^T/sqrt(dk)) of one utterance (rows row0..row0+len) as fp32
+ * atten[n_heads][len][len] — what MultiHeadedAttention.atten holds (network/encoder.py:82-84),
+ * consumed by calculate_all_attentions (network/fastspeech2.py:305-341). */
+int fs2_attention_dump(const void* qkv, float* atten, int row0, int len, int n_heads, int dk, int ld, int dtype,
+                       hipStream_t stream);
+
+/* out[m,j] = x[m,:] . W[j,:] + b[j], nout <= 8, fp32 — the predictors' final nn.Linear
+ * (network/variance_adaptor.py:78, :115 with repair D5). */
+int fs2_rowdot(const float* x, const float* W, const float* b, float* out, int M, int C, int nout,
+               hipStream_t stream);
+
+/* dur[m] = (int) clamp(round_half_even(exp(logd[m]) - 1), 0) — DurationPredictor.inference,
+ * network/variance_adaptor.py:135. */
+int fs2_duration_round(const float* logd, int* dur, int M, hipStream_t stream);
+
+/* LengthRegulator planning (network/variance_adaptor.py:13-31): per utterance, optional
+ * round(d * control) (:18-19), all-zero row -> ones (:28-30), inclusive scan `cum`, frame counts
+ * `olens` and frame offsets `cu_frames` [B+1].  dur_out receives the durations actually used. */
+int fs2_lr_plan(const int* dur_in, const int* cu_phone, float control, int* dur_out, int* cum, int* olens,
+                int* cu_frames, int B, hipStream_t stream);
+
+/* LengthRegulator expansion + pad_list (network/variance_adaptor.py:31, network/utils.py:50-56) into
+ * the packed frame matrix: out[f,:] = hs[cu_phone[b] + lr_index[f], :].  Also emits the frame-level
+ * row tables (seg, pos) and the index map lr_index (phone index inside the utterance). */
+int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phone, const int* cu_frames, int B,
+                  float* out_f32, void* out_t, int* frame_seg, int* frame_pos, int* lr_index, int Mf, int d,
+                  int dtype, hipStream_t stream);
+
+/* hs_va = hs + (energy_embed(e*escale) + pitch_embed(p*pscale)) for kernel-size-1 VarianceEmbedding
+ * (network/variance_adaptor.py:35-51, :203-206), then the decoder positional encoding
+ * out = hs_va * xscale + alpha * pe[pos] (network/encoder.py:216-219).  hs_va / out_f32 / out_t may be NULL
+ * (at least one of out_f32, out_t is required). */
+int fs2_variance_add_posenc(const float* hs, const float* pitch, const float* energy, const float* Wp,
+                            const float* bp, const float* We, const float* be, float pscale, float escale,
+                            const float* pe, const int* pos, float xscale, float alpha, float* hs_va,
+                            float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
+                            hipStream_t stream);
+
+/* packed [M,C] <-> zero-padded [B,Tmax,C] (pad_list, network/utils.py:50-56). */
+int fs2_unpack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C, hipStream_t stream);
+int fs2_pack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C, int M,
+                    hipStream_t stream);
+
+/* fp32 -> T copy (weight packing). */
+int fs2_cast(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FS2_HIP_H */

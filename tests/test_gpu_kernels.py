@@ -1,0 +1,274 @@
+"""-m gpu: each HIP kernel, called through the C ABI (ctypes), against the CPU oracle /
+plain torch fp32 on the same seeded inputs.  Integer outputs bit-exact; fp32 kernels to 1e-4
+relative-to-scale; bf16 kernels against the same math on bf16-rounded operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fastspeech2_amd import hip
+from fastspeech2_amd.hip import call, ptr, stream
+from oracle import fs2_oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _cu(lens):
+    cu = np.zeros(len(lens) + 1, np.int32)
+    cu[1:] = np.cumsum(lens)
+    return cu
+
+
+def _seg_tables(lens):
+    cu = _cu(lens)
+    M = int(cu[-1])
+    cu_d = torch.from_numpy(cu).to(DEV)
+    seg = torch.empty((max(M, 1), 2), dtype=torch.int32, device=DEV)
+    pos = torch.empty((max(M, 1),), dtype=torch.int32, device=DEV)
+    call("fs2_build_seg", ptr(cu_d), len(lens), ptr(seg), ptr(pos), M, stream())
+    return cu, cu_d, seg, pos
+
+
+def test_build_seg():
+    lens = [3, 1, 0, 7, 130]
+    cu, cu_d, seg, pos = _seg_tables(lens)
+    exp_seg, exp_pos = [], []
+    for b, L in enumerate(lens):
+        for t in range(L):
+            exp_seg.append([cu[b], cu[b + 1]])
+            exp_pos.append(t)
+    assert seg.cpu().numpy().tolist() == exp_seg
+    assert pos.cpu().numpy().tolist() == exp_pos
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("taps,cin,n,lens", [
+    (1, 64, 192, [5, 130, 1]),
+    (9, 64, 128, [1, 3, 200, 17, 4]),
+    (3, 96, 96, [40, 2, 90]),
+    (9, 256, 1024, [300, 75]),
+    (9, 1024, 256, [150, 140]),
+    (1, 256, 80, [257]),
+    (5, 128, 20, [33, 31]),
+])
+def test_conv_gemm(dtype, taps, cin, n, lens):
+    code = hip.DTYPE_CODE[dtype]
+    tdt = hip.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(taps * 1000 + cin + n)
+    M = sum(lens)
+    x = torch.randn(M, cin, generator=g)
+    w = torch.randn(n, cin, taps, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(n, generator=g) * 0.1
+    res = torch.randn(M, n, generator=g)
+    xq, wq = x.to(tdt).float(), w.to(tdt).float()
+    # oracle: per-utterance conv1d with zero "same" padding (network/encoder.py:16-30)
+    outs, r0 = [], 0
+    for L in lens:
+        xi = xq[r0:r0 + L].t().unsqueeze(0)
+        outs.append(F.conv1d(xi.double(), wq.double(), b.double(), padding=(taps - 1) // 2).squeeze(0).t())
+        r0 += L
+    ref = torch.cat(outs, 0)
+    _, _, seg, _ = _seg_tables(lens)
+    xd = x.to(DEV, tdt).contiguous()
+    wd = w.permute(2, 0, 1).to(DEV, tdt).contiguous()
+    bd, rd = b.to(DEV), res.to(DEV)
+    tol = 2e-5 if dtype == "fp32" else 2e-3   # bf16: only fp32 accumulation order differs
+    for relu, use_res, out_f32 in [(False, False, True), (True, False, False), (False, True, True)]:
+        out = torch.empty((M, n), device=DEV, dtype=torch.float32 if out_f32 else tdt)
+        call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), ptr(rd) if use_res else None, ptr(out),
+             ptr(seg) if taps > 1 else None, M, n, cin, taps, cin, n, n, int(relu), int(out_f32), code, stream())
+        exp = ref.clone()
+        if relu:
+            exp = exp.clamp_min(0)
+        if use_res:
+            exp = exp + res.double()
+        got = out.float().cpu().double()
+        t = tol if out_f32 or dtype == "fp32" else 1e-2   # + output rounding to bf16
+        err = (got - exp).abs().max().item()
+        assert err <= t * max(1.0, exp.abs().max().item()), (relu, use_res, out_f32, err)
+
+
+@pytest.mark.parametrize("C", [64, 256, 384, 1024])
+def test_layernorm(C):
+    g = torch.Generator().manual_seed(C)
+    M = 77
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = fs2_oracle.layer_norm(x, w, b)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    o32 = torch.empty_like(xd)
+    obf = torch.empty((M, C), device=DEV, dtype=torch.bfloat16)
+    call("fs2_layernorm", ptr(xd), ptr(wd), ptr(bd), ptr(o32), ptr(obf), M, C, 1e-12, hip.BF16, stream())
+    assert (o32.cpu() - ref).abs().max().item() <= 2e-5
+    assert (obf.float().cpu() - ref).abs().max().item() <= 4e-2
+    # a constant row: variance 0, eps 1e-12 -> output = bias (network/utils.py:41)
+    xc = torch.full((2, C), 2.5, device=DEV)
+    oc = torch.empty_like(xc)
+    call("fs2_layernorm", ptr(xc), ptr(wd), ptr(bd), ptr(oc), None, 2, C, 1e-12, hip.F32, stream())
+    assert torch.allclose(oc.cpu(), b.expand(2, C), atol=1e-6)
+
+
+@pytest.mark.parametrize("nout,C", [(1, 256), (4, 384), (1, 64)])
+def test_rowdot(nout, C):
+    g = torch.Generator().manual_seed(nout + C)
+    M = 45
+    x, W, b = torch.randn(M, C, generator=g), torch.randn(nout, C, generator=g), torch.randn(nout, generator=g)
+    out = torch.empty((M, nout), device=DEV)
+    call("fs2_rowdot", ptr(x.to(DEV)), ptr(W.to(DEV)), ptr(b.to(DEV)), ptr(out), M, C, nout, stream())
+    assert (out.cpu() - F.linear(x, W, b)).abs().max().item() <= 1e-4
+
+
+def test_duration_round_matches_oracle():
+    # values at and around the .5 boundaries: round-half-to-even, clamp at 0, negatives
+    vals = [math.log(1.5), math.log(2.5), math.log(3.5), -3.0, 0.0, 2.0, 5.0, math.log(1.49999), math.log(7.67)]
+    g = torch.Generator().manual_seed(0)
+    logd = torch.cat([torch.tensor(vals), torch.randn(4000, generator=g) * 1.5 + 1.0]).float()
+    exp = fs2_oracle.duration_round(logd)
+    dur = torch.empty((logd.numel(),), dtype=torch.int32, device=DEV)
+    call("fs2_duration_round", ptr(logd.to(DEV)), ptr(dur), logd.numel(), stream())
+    got = dur.cpu().long()
+    # the device exp may differ from the host exp in the last ulp: only entries whose exp(x)-1 is
+    # within 1e-4 of a .5 boundary may legitimately differ
+    frac = (logd.double().exp() - 1.0)
+    margin = (frac - frac.floor() - 0.5).abs()
+    bad = (got != exp) & (margin > 1e-4)
+    assert not bad.any()
+    assert (got[:len(vals)] == exp[:len(vals)]).sum() >= len(vals) - 1
+
+
+@pytest.mark.parametrize("control", [1.0, 0.8, 1.3])
+def test_length_regulator_bit_exact(control):
+    rng = np.random.Generator(np.random.PCG64(5))
+    lens = [1, 9, 300, 4, 17, 6]
+    d = 64
+    durs = [rng.integers(0, 9, size=L) for L in lens]
+    durs[3][:] = 0                       # D9: all-zero row
+    durs[1][0] = 0
+    durs[2][::3] = 0
+    cu = _cu(lens)
+    Mp = int(cu[-1])
+    hs = torch.randn(Mp, d)
+    dur_in = torch.from_numpy(np.concatenate(durs).astype(np.int32)).to(DEV)
+    cu_d = torch.from_numpy(cu).to(DEV)
+    B = len(lens)
+    dur_used = torch.empty(Mp, dtype=torch.int32, device=DEV)
+    cum = torch.empty(Mp, dtype=torch.int32, device=DEV)
+    olens = torch.empty(B, dtype=torch.int32, device=DEV)
+    cu_f = torch.empty(B + 1, dtype=torch.int32, device=DEV)
+    call("fs2_lr_plan", ptr(dur_in), ptr(cu_d), control, ptr(dur_used), ptr(cum), ptr(olens), ptr(cu_f), B, stream())
+    exp_idx, exp_d = [], []
+    for b in range(B):
+        ds = fs2_oracle.scale_durations(durs[b], control)
+        idx, dd = fs2_oracle.length_regulate_index(ds)
+        exp_idx.append(idx)
+        exp_d.append(dd)
+    exp_olens = [len(i) for i in exp_idx]
+    assert olens.cpu().tolist() == exp_olens
+    assert cu_f.cpu().tolist() == _cu(exp_olens).tolist()
+    assert dur_used.cpu().tolist() == np.concatenate(exp_d).tolist()
+    Mf = sum(exp_olens)
+    out = torch.empty((Mf, d), device=DEV)
+    outb = torch.empty((Mf, d), device=DEV, dtype=torch.bfloat16)
+    seg = torch.empty((Mf, 2), dtype=torch.int32, device=DEV)
+    pos = torch.empty(Mf, dtype=torch.int32, device=DEV)
+    lri = torch.empty(Mf, dtype=torch.int32, device=DEV)
+    call("fs2_lr_gather", ptr(hs.to(DEV)), ptr(cum), ptr(cu_d), ptr(cu_f), B, ptr(out), ptr(outb), ptr(seg), ptr(pos),
+         ptr(lri), Mf, d, hip.BF16, stream())
+    assert lri.cpu().tolist() == np.concatenate(exp_idx).tolist()
+    exp_rows = torch.cat([hs[cu[b]:cu[b + 1]][torch.from_numpy(exp_idx[b])] for b in range(B)], 0)
+    assert torch.equal(out.cpu(), exp_rows)                      # a copy: bit-exact
+    assert torch.equal(outb.cpu(), exp_rows.to(torch.bfloat16))
+    assert pos.cpu().tolist() == [t for L in exp_olens for t in range(L)]
+    cf = _cu(exp_olens)
+    assert seg.cpu().tolist() == [[cf[b], cf[b + 1]] for b, L in enumerate(exp_olens) for _ in range(L)]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("h,dk,lens", [(2, 32, [1, 70, 5]), (2, 64, [129, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 64])])
+def test_attention(dtype, h, dk, lens):
+    code = hip.DTYPE_CODE[dtype]
+    tdt = hip.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(h * 100 + dk)
+    d = h * dk
+    M = sum(lens)
+    qkv = torch.randn(M, 3 * d, generator=g)
+    qkv[:, :d] *= 2.0                      # peaky softmax rows
+    qq = qkv.to(tdt).float()
+    outs, r0 = [], 0
+    for L in lens:
+        q = qq[r0:r0 + L, :d].view(L, h, dk).transpose(0, 1).double()
+        k = qq[r0:r0 + L, d:2 * d].view(L, h, dk).transpose(0, 1).double()
+        v = qq[r0:r0 + L, 2 * d:].view(L, h, dk).transpose(0, 1).double()
+        a = torch.softmax(q @ (k.transpose(-2, -1) / math.sqrt(dk)), -1)   # network/encoder.py:77-84
+        outs.append((a @ v).transpose(0, 1).reshape(L, d))
+        r0 += L
+    ref = torch.cat(outs, 0)
+    cu_d = torch.from_numpy(_cu(lens)).to(DEV)
+    qd = qkv.to(DEV, tdt).contiguous()
+    ctx = torch.empty((M, d), device=DEV, dtype=tdt)
+    call("fs2_attention", ptr(qd), ptr(ctx), ptr(cu_d), len(lens), max(lens), h, dk, 3 * d, d, code, stream())
+    err = (ctx.float().cpu().double() - ref).abs().max().item()
+    assert err <= (2e-5 if dtype == "fp32" else 3e-2), err
+    # debug dump of the softmax matrix (calculate_all_attentions)
+    L0 = lens[0]
+    att = torch.empty((h, L0, L0), device=DEV)
+    call("fs2_attention_dump", ptr(qd), ptr(att), 0, L0, h, dk, 3 * d, code, stream())
+    q = qq[:L0, :d].view(L0, h, dk).transpose(0, 1)
+    k = qq[:L0, d:2 * d].view(L0, h, dk).transpose(0, 1)
+    a = torch.softmax(q @ (k.transpose(-2, -1) / math.sqrt(dk)), -1)
+    assert (att.cpu() - a).abs().max().item() <= 1e-4
+
+
+def test_embed_and_variance_add():
+    g = torch.Generator().manual_seed(3)
+    d, idim, M = 64, 30, 50
+    emb = torch.randn(idim, d, generator=g)
+    ids = torch.randint(0, idim, (M,), generator=g)
+    pos = torch.randint(0, 40, (M,), generator=g, dtype=torch.int32)
+    pe = fs2_oracle.posenc_table(64, d)
+    out = torch.empty((M, d), device=DEV)
+    call("fs2_embed_posenc", ptr(ids.to(DEV)), ptr(pos.to(DEV)), ptr(emb.to(DEV)), ptr(pe.to(DEV)), math.sqrt(d), 1.0,
+         ptr(out), None, M, d, idim, hip.F32, stream())
+    exp = emb[ids] * math.sqrt(d) + pe[pos.long()]
+    assert (out.cpu() - exp).abs().max().item() <= 1e-5
+    hs, p, e = torch.randn(M, d, generator=g), torch.randn(M, 4, generator=g), torch.randn(M, 1, generator=g)
+    Wp, bp = torch.randn(d, 4, generator=g), torch.randn(d, generator=g)
+    We, be = torch.randn(d, 1, generator=g), torch.randn(d, generator=g)
+    hv = torch.empty((M, d), device=DEV)
+    o2 = torch.empty((M, d), device=DEV)
+    ob = torch.empty((M, d), device=DEV, dtype=torch.bfloat16)
+    call("fs2_variance_add_posenc", ptr(hs.to(DEV)), ptr(p.to(DEV)), ptr(e.to(DEV)), ptr(Wp.to(DEV)), ptr(bp.to(DEV)),
+         ptr(We.to(DEV)), ptr(be.to(DEV)), 1.0, 1.0, ptr(pe.to(DEV)), ptr(pos.to(DEV)), 1.0, 0.7, ptr(hv), ptr(o2),
+         ptr(ob), M, d, 4, 1, hip.BF16, stream())
+    exp_hv = hs + ((e @ We.t() + be) + (p @ Wp.t() + bp))
+    assert (hv.cpu() - exp_hv).abs().max().item() <= 1e-5
+    assert (o2.cpu() - (exp_hv + 0.7 * pe[pos.long()])).abs().max().item() <= 1e-5
+    assert (ob.float().cpu() - o2.cpu()).abs().max().item() <= 5e-2
+
+
+def test_pack_unpack_roundtrip():
+    lens = [3, 7, 1]
+    cu = _cu(lens)
+    M, C, B, T = int(cu[-1]), 8, 3, 7
+    x = torch.randn(M, C, device=DEV)
+    cu_d = torch.from_numpy(cu).to(DEV)
+    padded = torch.full((B, T, C), 9.0, device=DEV)
+    call("fs2_unpack_padded", ptr(x), ptr(cu_d), ptr(padded), B, T, C, stream())
+    for b, L in enumerate(lens):
+        assert torch.equal(padded[b, :L], x[cu[b]:cu[b + 1]])
+        assert (padded[b, L:] == 0).all()
+    back = torch.empty_like(x)
+    call("fs2_pack_padded", ptr(padded), ptr(cu_d), ptr(back), B, T, C, M, stream())
+    assert torch.equal(back, x)
+
+
+def test_bad_arguments_are_rejected():
+    x = torch.zeros(8, 12, device=DEV)
+    with pytest.raises(hip.HipError):
+        call("fs2_conv_gemm", ptr(x), ptr(x), None, None, ptr(x), None, 8, 8, 12, 2, 12, 8, 8, 0, 1, 0, stream())
+    with pytest.raises(hip.HipError):
+        call("fs2_attention", ptr(x), ptr(x), ptr(x), 1, 8, 1, 48, 144, 48, 0, stream())

@@ -1,0 +1,170 @@
+"""-m gpu: the whole forward path (FeedForwardTransformer on the HIP engine) against the golden
+vectors of the repaired reference and against the CPU oracle.
+
+Bars (BASELINE.json north_star): durations and LengthRegulator indices bit-exact, mel within
+1e-3 max-abs in fp32.  bf16: durations are teacher-forced from the oracle (a bf16 encoder may
+legitimately flip a rounding), mel tolerance BF16_MEL_TOL stated below."""
+import numpy as np
+import pytest
+import torch
+
+from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer
+from oracle import fs2_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+FP32_MEL_TOL = 1e-3       # north_star
+BF16_MEL_TOL = 0.15       # max-abs on mel values of O(1..3); bf16 operands (8-bit mantissa) through 8 blocks
+BF16_MEL_RMS_TOL = 0.03
+
+
+def build_model(meta, precision="fp32", encoder_dtype=None):
+    idim, odim, kw = helpers.split_cfg(meta["cfg"])
+    model = FeedForwardTransformer(idim, odim, **kw)
+    model.load_state_dict(helpers.golden_state_dict(meta), strict=True)
+    model.eval().cuda()
+    model.set_precision(precision, encoder_dtype)
+    return model
+
+
+@pytest.mark.parametrize("name", helpers.INFER_CASES)
+def test_fp32_matches_reference_golden(name):
+    z, meta = helpers.load_golden(name)
+    model = build_model(meta)
+    dc = meta["duration_control"]
+    xs = [torch.from_numpy(z["ids_%d" % i]) for i in range(meta["n"])]
+    # per utterance through the reference API
+    for i, x in enumerate(xs):
+        mel = model.inference(x.cuda(), None, duration_control=dc).cpu().numpy()
+        assert mel.shape == z["mel_%d" % i].shape
+        assert np.abs(mel - z["mel_%d" % i]).max() <= FP32_MEL_TOL
+    # the same utterances as ONE ragged batch: every row must equal its batch-1 result
+    out = model.infer_batch(xs, duration_control=dc)
+    pk = out["packed"]
+    cu_p = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    cu_f = np.concatenate([[0], np.cumsum(pk["olens"])])
+    for i in range(meta["n"]):
+        assert pk["olens"][i] == int(z["frames_%d" % i])
+        assert np.array_equal(pk["durations_pred"].cpu().numpy()[cu_p[i]:cu_p[i + 1]], z["dur_pred_%d" % i])
+        if dc == 1.0:
+            assert np.array_equal(pk["durations"].cpu().numpy()[cu_p[i]:cu_p[i + 1]], z["dur_after_lr_%d" % i])
+        idx, _ = fs2_oracle.length_regulate_index(fs2_oracle.scale_durations(z["dur_pred_%d" % i], dc))
+        assert np.array_equal(pk["lr_index"].cpu().numpy()[cu_f[i]:cu_f[i + 1]], idx)
+        T = pk["olens"][i]
+        assert np.abs(out["mel"][i, :T].cpu().numpy() - z["mel_%d" % i]).max() <= FP32_MEL_TOL
+        assert (out["mel"][i, T:] == 0).all()
+        assert np.abs(pk["enc_out"].cpu().numpy()[cu_p[i]:cu_p[i + 1]] - z["enc_out_%d" % i]).max() <= 1e-3
+        assert np.abs(pk["pitch"].cpu().numpy()[cu_f[i]:cu_f[i + 1]] - z["pitch_%d" % i]).max() <= 1e-3
+        assert np.abs(pk["energy"].cpu().numpy()[cu_f[i]:cu_f[i + 1]] - z["energy_%d" % i]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("name", ["tiny_conv9_plain", "tiny_conv3_mixed_ln", "baseline_4x4"])
+def test_bf16_teacher_forced_durations(name):
+    z, meta = helpers.load_golden(name)
+    model = build_model(meta, "bf16")
+    eng = model.engine()
+    for i in range(meta["n"]):
+        x = torch.from_numpy(z["ids_%d" % i]).cuda()
+        ds = torch.from_numpy(z["dur_after_lr_%d" % i].astype(np.int32)).cuda()
+        out = eng.forward(x, [x.numel()], ds=ds)
+        mel = out["mel"].cpu().numpy()
+        ref = z["mel_%d" % i]
+        assert mel.shape == ref.shape
+        assert np.abs(mel - ref).max() <= BF16_MEL_TOL
+        assert np.sqrt(np.mean((mel - ref) ** 2)) <= BF16_MEL_RMS_TOL
+
+
+def test_bf16_with_fp32_encoder_keeps_durations_exact():
+    z, meta = helpers.load_golden("baseline_4x4")
+    model = build_model(meta, "bf16", encoder_dtype="fp32")
+    xs = [torch.from_numpy(z["ids_%d" % i]) for i in range(meta["n"])]
+    out = model.infer_batch(xs)
+    cu_p = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    for i in range(meta["n"]):
+        assert np.array_equal(out["packed"]["durations_pred"].cpu().numpy()[cu_p[i]:cu_p[i + 1]], z["dur_pred_%d" % i])
+        T = int(z["frames_%d" % i])
+        assert np.abs(out["mel"][i, :T].cpu().numpy() - z["mel_%d" % i]).max() <= BF16_MEL_TOL
+
+
+@pytest.mark.parametrize("name", helpers.TRAIN_CASES)
+def test_training_forward_loss_matches_reference(name):
+    z, meta = helpers.load_golden(name)
+    model = build_model(meta)
+    t = lambda k: torch.from_numpy(z[k])
+    loss = model(t("xs"), t("ilens"), t("ys"), t("olens"), t("ds"), t("ps"), t("es"))
+    obs = model.reporter.observation
+    for k in ("l1_loss", "duration_loss", "pitch_loss", "energy_loss", "loss"):
+        assert abs(obs[k] - meta["losses"][k]) <= 1e-4 * max(1.0, abs(meta["losses"][k])), k
+    assert abs(float(loss) - meta["loss"]) <= 1e-4 * abs(meta["loss"])
+    # _forward (non-inference) hands back padded (before, after, d_outs, p_outs, e_outs)
+    outs = model._forward(t("xs"), t("ilens"), t("olens"), t("ds"), t("ps"), t("es"))
+    assert outs[0].shape == (z["xs"].shape[0], int(z["olens"].max()), meta["cfg"]["odim"])
+    assert outs[2].shape == tuple(z["xs"].shape) and outs[3].shape[-1] == 4 and outs[4].shape[-1] == 1
+
+
+def test_ragged_batch_vs_oracle_and_attention_dump():
+    """Seeded inputs beyond the goldens: the HIP path vs the CPU oracle on a ragged batch, plus
+    calculate_all_attentions against the oracle's softmax matrices."""
+    z, meta = helpers.load_golden("tiny_conv9_plain")
+    model = build_model(meta)
+    sd, cfg = helpers.golden_state_dict(meta), helpers.oracle_cfg(meta)
+    rng = np.random.Generator(np.random.PCG64(99))
+    xs = [torch.from_numpy(rng.integers(1, cfg["idim"], size=L)) for L in (13, 2, 29, 8)]
+    out = model.infer_batch(xs)
+    for i, x in enumerate(xs):
+        o = fs2_oracle.infer_one(sd, cfg, x)
+        T = o["mel"].shape[0]
+        assert out["olens"][i] == T
+        assert torch.equal(out["durations"][i, :len(x)].cpu(), o["durations"])
+        assert (out["mel"][i, :T].cpu() - o["mel"]).abs().max().item() <= FP32_MEL_TOL
+    # teacher-forced attention dump
+    ils = [len(x) for x in xs]
+    ds = [torch.from_numpy(rng.integers(0, 4, size=L)) for L in ils]
+    for dd in ds:
+        dd[0] += 1
+    ols = [int(dd.sum()) for dd in ds]
+    B, Tp, Tm = len(xs), max(ils), max(ols)
+    pad = lambda lst, T, shape=(): torch.stack([torch.cat([v, v.new_zeros((T - v.shape[0],) + shape)]) for v in lst])
+    ps = [torch.from_numpy(rng.standard_normal((L, 4)).astype(np.float32)) for L in ols]
+    es = [torch.from_numpy(rng.standard_normal((L, 1)).astype(np.float32)) for L in ols]
+    att = model.calculate_all_attentions(pad(xs, Tp), torch.tensor(ils), torch.zeros(B, Tm, cfg["odim"]),
+                                         torch.tensor(ols), pad(ds, Tp), pad(ps, Tm, (4,)), pad(es, Tm, (1,)))
+    assert set(att) == {"encoder.encoders.0.self_atten", "encoder.encoders.1.self_atten",
+                        "decoder.encoders.0.self_atten", "decoder.encoders.1.self_atten", "predicted_fbank"}
+    for b in range(B):
+        ea, da, mel = fs2_oracle.attentions_one(sd, cfg, xs[b], ds[b], ps[b], es[b])
+        for li in range(2):
+            assert np.abs(att["encoder.encoders.%d.self_atten" % li][b] - ea[li].numpy()).max() <= 1e-4
+            assert np.abs(att["decoder.encoders.%d.self_atten" % li][b] - da[li].numpy()).max() <= 1e-4
+        assert np.abs(att["predicted_fbank"][b] - mel.numpy().T).max() <= FP32_MEL_TOL
+
+
+def test_full_size_properties_bf16():
+    """BASELINE config-2 size (32 length-bucketed utterances, BASELINE dims): size-independent
+    properties — batch result == per-utterance result for sampled rows, frame counts == sum of
+    durations, LengthRegulator index map monotone and consistent with the durations."""
+    from fastspeech2_amd import synth
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = synth.synth_state_dict(80, 80, 1234, dur_bias=float(np.log(7.67)), dur_w_scale=0.15, **kw)
+    model = FeedForwardTransformer(80, 80, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval().cuda().set_precision("bf16")
+    xs = [torch.from_numpy(x) for x in synth.synth_utterances(32, 0)]
+    out = model.infer_batch(xs)
+    pk = out["packed"]
+    dur = pk["durations"].cpu().numpy()
+    cu_p = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    cu_f = np.concatenate([[0], np.cumsum(pk["olens"])])
+    lri = pk["lr_index"].cpu().numpy()
+    for b in range(32):
+        d_b = dur[cu_p[b]:cu_p[b + 1]]
+        assert pk["olens"][b] == int(d_b.sum())
+        idx, _ = fs2_oracle.length_regulate_index(d_b)
+        assert np.array_equal(lri[cu_f[b]:cu_f[b + 1]], idx)
+    assert torch.isfinite(out["mel"]).all()
+    for b in (0, 13, 31):                      # batch row == the same utterance alone
+        alone = model.infer_batch([xs[b]])
+        if np.array_equal(alone["packed"]["durations"].cpu().numpy(), dur[cu_p[b]:cu_p[b + 1]]):
+            T = pk["olens"][b]
+            assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= 1e-5
