@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel frames/s of the FastSpeech2 forward path (phone ids resident in HBM ->
+mel resident in HBM) on BASELINE.json config 2: the BASELINE architecture (4+4 FFT blocks, d=256,
+2 heads, conv k=9 FFN, U=1024), random-init, one batch of 32 length-bucketed synthetic utterances
+(~120 phones -> ~800 mel frames) per GPU, bf16 MFMA operands.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one forward over one 32-utterance batch.  Utterances are independent, so N GPUs run N
+different batches with no data-path collective (weak scaling); only the timing is reduced (MAX).
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the conv-FFN implicit GEMM, timed
+with HIP events on its launch stream in a second, separately timed pass) and `cpu_baseline` (the CPU
+oracle, kind "port", timed on this box's host cores on the same batch).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from fastspeech2_amd import synth                                   # noqa: E402
+from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md chip table (dense)
+HOP_SECONDS = 256.0 / 22050.0                    # assumed hop (reference defines none)
+BATCH = 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--encoder-dtype", default=None, choices=[None, "bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_model(dtype, encoder_dtype, device):
+    kw = dict(synth.BASELINE_OVERRIDES)
+    model = FeedForwardTransformer(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
+    sd = synth.bench_state_dict()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval().to(device)
+    model.set_precision(dtype, encoder_dtype)
+    return model, sd, kw
+
+
+def rank_batch(world, rank):
+    """world*32 utterances (seed 0), length-sorted, dealt round-robin: every rank gets one
+    32-utterance bucket with a near-identical length profile."""
+    utts = synth.synth_utterances(BATCH * world, 0, idim=synth.BENCH_IDIM)
+    return utts[rank::world]
+
+
+def cpu_baseline(sd_np, kw, xs, passes):
+    from oracle import fs2_oracle                  # checker used as the CPU baseline ("port")
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    cfg = fs2_oracle.full_cfg(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
+    fs2_oracle.infer_one(sd, cfg, torch.from_numpy(xs[-1]))         # warm-up
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(passes):
+        for x in xs:
+            frames += fs2_oracle.infer_one(sd, cfg, torch.from_numpy(x))["mel"].shape[0]
+    dt = time.perf_counter() - t0
+    return dict(value=frames / dt, unit="mel frames/s", cores=threads, kind="port",
+                sample="%d pass(es) over the same 32-utterance batch, fp32 torch-CPU oracle, %.1f s"
+                       % (passes, dt))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    model, sd_np, kw = build_model(args.dtype, args.encoder_dtype, dev)
+    eng = model.engine()
+    xs = rank_batch(world, rank)
+    ilens = [len(x) for x in xs]
+    ids = torch.from_numpy(np.concatenate(xs)).to(dev)
+
+    def step():
+        return eng.forward(ids, ilens)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    frames = float(sum(out["olens"]))
+    flops = synth.algorithmic_flops(ilens, out["olens"])
+    stats = torch.tensor([elapsed, frames, flops], dtype=torch.float64, device=dev)
+    if dist is not None:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        frames, flops = float(stats[1]), float(stats[2])
+
+    # ---- roofline of the dominant kernel (conv-FFN implicit GEMM), HIP events on the launch stream
+    roofline = None
+    if rank == 0:
+        eng.profile = []
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        torch.cuda.synchronize()
+        recs = eng.profile
+        eng.profile = None
+        t_ms = sum(e0.elapsed_time(e1) for (_, _, _, _, e0, e1) in recs)
+        fl = sum(2.0 * M * N * K for (_, M, N, K, _, _) in recs)
+        n = len(recs)
+        achieved = fl / (t_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.dtype]
+        roofline = dict(bound="mfma", kernel="fs2::conv_gemm_kernel<%s> (FFN conv k=9, both convs)" % args.dtype,
+                        achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                        traffic=None, launches=n, avg_launch_us=round(t_ms * 1e3 / n, 2),
+                        flops_per_launch=fl / n)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sd_np, kw, xs, args.cpu_passes)
+
+    if rank == 0:
+        value = frames * args.steps / elapsed
+        line = {
+            "metric": "mel frames/sec (node) at batch 32 per GPU",
+            "value": round(value, 1), "unit": "mel frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 32 length-bucketed utterances/GPU (~120 phones -> ~800 mel "
+                                   "frames), 4+4 FFT blocks d=256 h=2 conv-k9 U=1024, random-init, idim=odim=80",
+                       "frames_per_step": frames, "phones_per_step": float(sum(ilens)) * world,
+                       "encoder_dtype": args.encoder_dtype or args.dtype,
+                       "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),
+                       "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
+                       "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["config"]["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

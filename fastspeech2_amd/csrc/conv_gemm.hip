@@ -8,27 +8,28 @@
 // padding=(k-1)//2; SURVEY.md §7 "varlen halos").  taps == 1 is a plain Linear
 // (network/encoder.py:39-44, :57-60; network/fastspeech2.py:158).
 //
-// Tiling (gfx950): 256 threads = 4 waves as 2(M) x 2(N); block tile 128(M) x 128(N); each wave
-// 64 x 64 = 4 x 4 MFMA 16x16 tiles.  Per channel-chunk the X tile plus its (taps-1)-row halo is
-// staged ONCE in LDS and re-used by all taps as shifted row views (no im2col); the W tile of
-// (tap, chunk) is streamed.  Both are double-buffered with register prefetch: global loads for
-// step s+1 are issued before the MFMAs of step s and written to the other LDS buffer after them
-// (one barrier per step).  MFMA operand roles are swapped (A = W rows, B = X rows) so a lane
-// ends up with 4 consecutive output channels of one token -> 16-byte epilogue accesses.
+// Structure (gfx950): 256 threads = 4 waves as 2(M) x 2(N); each wave MT x NT MFMA 16x16 tiles
+// (block tile 32MT x 32NT: 128x128 for the big frame-level GEMMs, 64x64 when the grid would not
+// fill the chip).  K is walked in (channel chunk, tap) steps of 128 bytes per row.  Per chunk the
+// X tile plus its (taps-1)-row halo is staged ONCE in LDS and re-used by every tap as a shifted
+// row view (no im2col buffer); the W tile of (tap, chunk) is streamed.  Both are double-buffered:
+// the loads of step s+1 are issued before the MFMAs of step s, one barrier per step.
+//   fast path  (Cin % chunk == 0): global_load_lds_dwordx4 (LDS-DMA, no VGPR / ds_write traffic)
+//   generic    (any Cin % 8 == 0): register staging with zero fill of the K tail
+// LDS images are unpadded 128-byte rows with the 16-byte slot index XOR-swizzled by the row so the
+// 16 rows of an MFMA fragment read hit 16 different bank groups; with LDS-DMA the swizzle is
+// applied to the per-lane SOURCE address (the LDS side of the DMA is lane-linear).
+// MFMA operand roles are swapped (A = W rows, B = X rows) and the W rows of a wave are fed in a
+// permuted order so that a lane ends up with 16 CONSECUTIVE output channels of one token:
+// 64-byte (f32) / 32-byte (bf16) contiguous epilogue accesses.
 #include "common.h"
 
 namespace fs2 {
 
-constexpr int CG_BM = 128;
-constexpr int CG_BN = 128;
 constexpr int CG_THREADS = 256;
 constexpr int CG_MAX_TAPS = 9;
-constexpr int CG_ROW_BYTES = 128;              // data bytes per LDS row (one channel chunk)
-constexpr int CG_ROW_STRIDE = CG_ROW_BYTES + 16;  // +16 B pad: conflict-free ds_read_b128
-constexpr int CG_XROWS = CG_BM + CG_MAX_TAPS - 1;
-constexpr int CG_X_BYTES = CG_XROWS * CG_ROW_STRIDE;
-constexpr int CG_W_BYTES = CG_BN * CG_ROW_STRIDE;
-constexpr int CG_LDS_BYTES = 2 * CG_X_BYTES + 2 * CG_W_BYTES;
+constexpr int CG_HALO = CG_MAX_TAPS - 1;
+constexpr int CG_ROWB = 128;  // bytes per LDS row = one channel chunk
 
 struct ConvGemmArgs {
     const void* X;       // [M, ldx] T
@@ -43,127 +44,129 @@ struct ConvGemmArgs {
     int n_tiles;
 };
 
-template <typename T>
+// 16-byte slot swizzles (see header comment)
+__device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int swz_w(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int MT, int NT, bool DMA>
 __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a) {
-    constexpr int EPV = 16 / sizeof(T);           // elements per 16-byte vector
-    constexpr int BKE = CG_ROW_BYTES / sizeof(T);  // channels per chunk (64 bf16 / 32 f32)
-    constexpr int KSTEPS = BKE / 32;               // fragment steps per chunk
-    constexpr int VPR = CG_ROW_BYTES / 16;         // 16-byte vectors per LDS row (8)
-    constexpr int FRAG_BYTES = 8 * sizeof(T);
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte slot
+    constexpr int BKE = CG_ROWB / (int)sizeof(T);   // channels per chunk (64 bf16 / 32 f32)
+    constexpr int KSTEPS = BKE / 32;                // fragment steps per chunk
+    constexpr int XROWS = BM + CG_HALO;
+    constexpr int X_BYTES = XROWS * CG_ROWB;
+    constexpr int W_BYTES = BN * CG_ROWB;
+    constexpr int X_INSTR = XROWS / 8;              // 1-KiB (8-row) pieces of the X image
+    constexpr int W_INSTR = BN / 8;
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    auto xs_buf = [&](int b) -> unsigned char* { return smem + b * CG_X_BYTES; };
-    auto ws_buf = [&](int b) -> unsigned char* { return smem + 2 * CG_X_BYTES + b * CG_W_BYTES; };
+    // [X buf0][X buf1][W buf0][W buf1]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, i = lane & 15;
 
-    // blocks that share W columns share `blockIdx % n_tiles` -> same XCD L2 under the round-robin
+    // blocks that share W columns have equal blockIdx % n_tiles -> same XCD L2 under round-robin
     // dispatch when n_tiles divides 8 or is a multiple of it (speed only)
     const int n_tile = blockIdx.x % a.n_tiles;
     const int m_tile = blockIdx.x / a.n_tiles;
-    const int m0 = m_tile * CG_BM;
-    const int n0 = n_tile * CG_BN;
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
     const int pad = (a.taps - 1) >> 1;
-    const int xrows = CG_BM + a.taps - 1;
     const int nchunks = (a.Cin + BKE - 1) / BKE;
     const int nsteps = nchunks * a.taps;
 
     const T* __restrict__ X = (const T*)a.X;
     const T* __restrict__ W = (const T*)a.W;
 
-    // per-lane validity window of tap shifts for each of its 4 token rows
-    int lo[4], hi[4];
+    // per-lane validity window of tap shifts for each of its token rows
+    int lo[MT], hi[MT];
     bool edge = false;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + i;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (16 * MT) + mt * 16 + i;
+        int l = 1, h = 0;
         if (m < a.M) {
+            l = 0;
             if (a.seg) {
                 const int2 s = a.seg[m];
-                lo[mt] = s.x - m;
-                hi[mt] = s.y - 1 - m;
-            } else {
-                lo[mt] = 0;
-                hi[mt] = 0;
+                l = s.x - m;
+                h = s.y - 1 - m;
             }
-        } else {
-            lo[mt] = 1;
-            hi[mt] = 0;
         }
-        edge |= (lo[mt] > -pad) | (hi[mt] < pad);
+        lo[mt] = l;
+        hi[mt] = h;
+        edge |= (l > -pad) | (h < pad);
     }
     const bool need_mask = __syncthreads_or(edge ? 1 : 0) != 0;
 
-    // ---- register-staged prefetch state ---------------------------------------------------
-    constexpr int XV = (CG_XROWS * VPR + CG_THREADS - 1) / CG_THREADS;  // 5
-    constexpr int WV = (CG_BN * VPR) / CG_THREADS;                      // 4
-    vec16 xreg[XV], wreg[WV];
-    const vec16 zero16 = {0u, 0u, 0u, 0u};
+    // ---- staging ----------------------------------------------------------------------------
+    // piece p (8 rows x 128 B) of an image: lane l -> row 8p + (l >> 3), slot (l & 7); the slot holds
+    // global chunk (slot ^ swz(row)).
+    const int prow = lane >> 3, pslot = lane & 7;
 
-    auto load_x = [&](int chunk) {
+    auto stage_x = [&](int chunk, int buf) __attribute__((always_inline)) {
+        unsigned char* dst = smem + buf * X_BYTES;
         const int c0 = chunk * BKE;
-#pragma unroll
-        for (int v = 0; v < XV; ++v) {
-            const int idx = tid + v * CG_THREADS;
-            const int r = idx / VPR, cv = idx % VPR;
+        for (int p = wave; p < X_INSTR; p += 4) {
+            const int r = 8 * p + prow;
             int gm = m0 - pad + r;
-            const int c = c0 + cv * EPV;
-            // rows outside [0, M) are never a valid tap source (masked), clamp the address only
-            gm = gm < 0 ? 0 : (gm >= a.M ? a.M - 1 : gm);
-            if (r < xrows && c < a.Cin)
-                xreg[v] = *(const vec16*)(X + (size_t)gm * a.ldx + c);
-            else
-                xreg[v] = zero16;
+            gm = gm < 0 ? 0 : (gm >= a.M ? a.M - 1 : gm);  // out-of-range rows are always masked
+            const int c = c0 + ((pslot ^ swz_x(r)) * EPV);
+            if constexpr (DMA) {
+                glds16(X + (size_t)gm * a.ldx + c, dst + p * 1024);
+            } else {
+                vec16 v = {0u, 0u, 0u, 0u};
+                if (c < a.Cin) v = *(const vec16*)(X + (size_t)gm * a.ldx + c);
+                *(vec16*)(dst + p * 1024 + lane * 16) = v;
+            }
         }
     };
-    auto store_x = [&](unsigned char* dst) {
-#pragma unroll
-        for (int v = 0; v < XV; ++v) {
-            const int idx = tid + v * CG_THREADS;
-            const int r = idx / VPR, cv = idx % VPR;
-            if (r < xrows) *(vec16*)(dst + r * CG_ROW_STRIDE + cv * 16) = xreg[v];
-        }
-    };
-    auto load_w = [&](int tap, int chunk) {
+    auto stage_w = [&](int tap, int chunk, int buf) __attribute__((always_inline)) {
+        unsigned char* dst = smem + 2 * X_BYTES + buf * W_BYTES;
         const int c0 = chunk * BKE;
         const T* wt = W + (size_t)tap * a.N * a.Cin;
 #pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int idx = tid + v * CG_THREADS;
-            const int r = idx / VPR, cv = idx % VPR;
-            const int n = n0 + r;
-            const int c = c0 + cv * EPV;
-            if (n < a.N && c < a.Cin)
-                wreg[v] = *(const vec16*)(wt + (size_t)n * a.Cin + c);
-            else
-                wreg[v] = zero16;
-        }
-    };
-    auto store_w = [&](unsigned char* dst) {
-#pragma unroll
-        for (int v = 0; v < WV; ++v) {
-            const int idx = tid + v * CG_THREADS;
-            const int r = idx / VPR, cv = idx % VPR;
-            *(vec16*)(dst + r * CG_ROW_STRIDE + cv * 16) = wreg[v];
+        for (int q = 0; q < W_INSTR / 4; ++q) {
+            const int p = wave + 4 * q;
+            const int r = 8 * p + prow;
+            int n = n0 + r;
+            n = n >= a.N ? a.N - 1 : n;                     // columns >= N are never stored
+            const int c = c0 + ((pslot ^ swz_w(r)) * EPV);
+            if constexpr (DMA) {
+                glds16(wt + (size_t)n * a.Cin + c, dst + p * 1024);
+            } else {
+                vec16 v = {0u, 0u, 0u, 0u};
+                if (c < a.Cin) v = *(const vec16*)(wt + (size_t)n * a.Cin + c);
+                *(vec16*)(dst + p * 1024 + lane * 16) = v;
+            }
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // prologue
-    load_x(0);
-    load_w(0, 0);
-    store_x(xs_buf(0));
-    store_w(ws_buf(0));
+    // W rows of this wave are consumed in the order  a -> (a >> 2) * (4 NT) + 4 nt + (a & 3)
+    // (a = A-operand row of tile nt), so lane group g ends up with channels 4 NT g .. 4 NT g + 4 NT - 1
+    const int wrow_base = wn * (16 * NT) + (i >> 2) * (4 * NT) + (i & 3);
+    const int xrow_base = wm * (16 * MT) + i;
+
+    stage_x(0, 0);
+    stage_w(0, 0, 0);
     __syncthreads();
 
     int xcur = 0, wcur = 0;
@@ -173,89 +176,173 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
         if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
         const bool has_next = (step + 1) < nsteps;
         const bool next_x = has_next && (ntap == 0);
-        if (has_next) load_w(ntap, nchunk);
-        if (next_x) load_x(nchunk);
+        if (DMA) {   // LDS-DMA prefetch of step+1 into the other buffers, in flight during the MFMAs
+            if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
+            if (next_x) stage_x(nchunk, xcur ^ 1);
+        }
 
-        const unsigned char* xs = xs_buf(xcur);
-        const unsigned char* ws = ws_buf(wcur);
+        const unsigned char* xs = smem + xcur * X_BYTES;
+        const unsigned char* ws = smem + 2 * X_BYTES + wcur * W_BYTES;
         const int shift = tap - pad;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            frag_t wf[4], xf[4];
-            const int koff = ks * 32 * (int)sizeof(T) + g * FRAG_BYTES;
+            frag_t wf[NT], xf[MT];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                wf[nt] = *(const frag_t*)(ws + (wn * 64 + nt * 16 + i) * CG_ROW_STRIDE + koff);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int r = wrow_base + 4 * nt;
+                const unsigned char* rowp = ws + r * CG_ROWB;
+                if constexpr (sizeof(T) == 2) {
+                    wf[nt] = *(const frag_t*)(rowp + (((ks * 4 + g) ^ swz_w(r)) << 4));
+                } else {
+                    const f32x4 v0 = *(const f32x4*)(rowp + (((2 * g) ^ swz_w(r)) << 4));
+                    const f32x4 v1 = *(const f32x4*)(rowp + (((2 * g + 1) ^ swz_w(r)) << 4));
+                    wf[nt] = (frag_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
+            }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                xf[mt] = *(const frag_t*)(xs + (wm * 64 + mt * 16 + i + tap) * CG_ROW_STRIDE + koff);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int r = xrow_base + mt * 16 + tap;
+                const unsigned char* rowp = xs + r * CG_ROWB;
+                if constexpr (sizeof(T) == 2) {
+                    xf[mt] = *(const frag_t*)(rowp + (((ks * 4 + g) ^ swz_x(r)) << 4));
+                } else {
+                    const f32x4 v0 = *(const f32x4*)(rowp + (((2 * g) ^ swz_x(r)) << 4));
+                    const f32x4 v1 = *(const f32x4*)(rowp + (((2 * g + 1) ^ swz_x(r)) << 4));
+                    xf[mt] = (frag_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
+            }
             if (need_mask) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     if (shift < lo[mt] || shift > hi[mt]) xf[mt] = frag_zero<T>();
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mma16(wf[nt], xf[mt], acc[mt][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(wf[nt], xf[mt], acc[mt][nt]);
         }
 
-        if (has_next) store_w(ws_buf(wcur ^ 1));
-        if (next_x) store_x(xs_buf(xcur ^ 1));
-        __syncthreads();
+        if (!DMA) {  // generic path: synchronous register staging of step+1 (odd shapes only)
+            if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
+            if (next_x) stage_x(nchunk, xcur ^ 1);
+        }
+        __syncthreads();   // also drains the LDS-DMA (vmcnt(0)) issued at the top of this step
         wcur ^= 1;
         if (next_x) xcur ^= 1;
         tap = ntap;
         chunk = nchunk;
     }
 
-    // ---- epilogue: lane (g, i) holds out[m = .. + i][n = .. + 4g + r], r = 0..3 ----------------
+    // ---- epilogue: lane (g, i) holds token m = .. + 16 mt + i, channels nb .. nb + 4 NT - 1 with
+    //      acc[mt][nt][r] <-> channel nb + 4 nt + r.  Loads are issued in batches (clamped
+    //      addresses, predicated use) so their latencies overlap. ------------------------------
+    const int nb = n0 + wn * (16 * NT) + g * (4 * NT);
     const bool vec_ok = ((a.N & 3) == 0) && ((a.ldo & 3) == 0) && (!a.res || (a.ldr & 3) == 0);
+    if (vec_ok) {
+        bool nok[NT];
+        int ncl[NT];
+        f32x4 bv[NT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + i;
-        if (m >= a.M) continue;
+        for (int nt = 0; nt < NT; ++nt) {
+            nok[nt] = (nb + 4 * nt) < a.N;
+            ncl[nt] = nok[nt] ? nb + 4 * nt : 0;
+            bv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (a.bias) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
-            if (n >= a.N) continue;
-            f32x4 v = acc[mt][nt];
-            if (vec_ok) {
-                if (a.bias) {
-                    const f32x4 b = *(const f32x4*)(a.bias + n);
-                    v += b;
-                }
-                if (a.relu) {
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4*)(a.bias + ncl[nt]);
+        }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                if (a.res) {
-                    const f32x4 rr = *(const f32x4*)(a.res + (size_t)m * a.ldr + n);
-                    v += rr;
-                }
-                if (a.out_f32) {
-                    *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
-                } else {
-                    T* o = (T*)a.out + (size_t)m * a.ldo + n;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wm * (16 * MT) + mt * 16 + i;
+            const bool mok = m < a.M;
+            const size_t mc = (size_t)(mok ? m : a.M - 1);
+            f32x4 v[NT];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
-                }
+            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + bv[nt];
+            if (a.relu) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] = fmaxf(v[nt][r], 0.f);
+            }
+            if (a.res) {
+                f32x4 rv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) rv[nt] = *(const f32x4*)(a.res + mc * a.ldr + ncl[nt]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) v[nt] += rv[nt];
+            }
+            if (a.out_f32) {
+                float* o = (float*)a.out + mc * a.ldo;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (mok && nok[nt]) *(f32x4*)(o + ncl[nt]) = v[nt];
             } else {
+                T* o = (T*)a.out + mc * a.ldo;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= a.N) continue;
-                    float s = v[r];
-                    if (a.bias) s += a.bias[n + r];
-                    if (a.relu) s = fmaxf(s, 0.f);
-                    if (a.res) s += a.res[(size_t)m * a.ldr + n + r];
-                    if (a.out_f32)
-                        ((float*)a.out)[(size_t)m * a.ldo + n + r] = s;
-                    else
-                        ((T*)a.out)[(size_t)m * a.ldo + n + r] = from_f32<T>(s);
+                for (int nt = 0; nt < NT; ++nt) {
+                    T t4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t4[r] = from_f32<T>(v[nt][r]);
+                    if (mok && nok[nt]) {
+                        if constexpr (sizeof(T) == 2)
+                            *(uint2*)(o + ncl[nt]) = *(const uint2*)t4;
+                        else
+                            *(f32x4*)(o + ncl[nt]) = *(const f32x4*)t4;
+                    }
                 }
             }
         }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wm * (16 * MT) + mt * 16 + i;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb + 4 * nt + r;
+                    if (n >= a.N) continue;
+                    float s = acc[mt][nt][r];
+                    if (a.bias) s += a.bias[n];
+                    if (a.relu) s = fmaxf(s, 0.f);
+                    if (a.res) s += a.res[(size_t)m * a.ldr + n];
+                    if (a.out_f32)
+                        ((float*)a.out)[(size_t)m * a.ldo + n] = s;
+                    else
+                        ((T*)a.out)[(size_t)m * a.ldo + n] = from_f32<T>(s);
+                }
+        }
     }
+}
+
+template <typename T, int MT, int NT, bool DMA>
+static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
+    constexpr int BM = 32 * MT, BN = 32 * NT;
+    constexpr int lds = 2 * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, DMA>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    a.n_tiles = (a.N + BN - 1) / BN;
+    const int m_tiles = (a.M + BM - 1) / BM;
+    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, DMA>), dim3(a.n_tiles * m_tiles), dim3(CG_THREADS), lds, stream, a);
+    FS2_CHECK_LAUNCH("fs2_conv_gemm");
+    return FS2_OK;
+}
+
+template <typename T>
+static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
+    constexpr int BKE = CG_ROWB / (int)sizeof(T);
+    const bool dma = (a.Cin % BKE) == 0;
+    const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool small = big_blocks < 384;   // would leave most of the 256 CUs idle: use 64x64 tiles
+    if (dma) return small ? launch_conv_gemm<T, 2, 2, true>(a, stream) : launch_conv_gemm<T, 4, 4, true>(a, stream);
+    return small ? launch_conv_gemm<T, 2, 2, false>(a, stream) : launch_conv_gemm<T, 4, 4, false>(a, stream);
 }
 
 }  // namespace fs2
@@ -282,20 +369,6 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
     ConvGemmArgs a;
     a.X = X; a.W = W; a.bias = bias; a.res = res; a.out = out; a.seg = (const int2*)seg;
     a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.ldx = ldx; a.ldr = ldr; a.ldo = ldo;
-    a.relu = relu; a.out_f32 = out_f32;
-    a.n_tiles = (N + CG_BN - 1) / CG_BN;
-    const int m_tiles = (M + CG_BM - 1) / CG_BM;
-    dim3 grid(a.n_tiles * m_tiles), block(CG_THREADS);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, CG_LDS_BYTES);
-        attr_set = true;
-    }
-    if (dtype == 0)
-        hipLaunchKernelGGL(conv_gemm_kernel<float>, grid, block, CG_LDS_BYTES, stream, a);
-    else
-        hipLaunchKernelGGL(conv_gemm_kernel<bf16_t>, grid, block, CG_LDS_BYTES, stream, a);
-    FS2_CHECK_LAUNCH("fs2_conv_gemm");
-    return FS2_OK;
+    a.relu = relu; a.out_f32 = out_f32; a.n_tiles = 1;
+    return dtype == 0 ? dispatch_conv_gemm<float>(a, stream) : dispatch_conv_gemm<bf16_t>(a, stream);
 }

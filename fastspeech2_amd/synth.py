@@ -150,3 +150,29 @@ def synth_utterances(n: int, seed: int, idim: int = 80, mean_len: float = 120.0,
     if sort:
         lens = np.sort(lens)[::-1]
     return [rng.integers(1, idim, size=int(L), dtype=np.int64) for L in lens]
+
+
+# bench / config-2 model: BASELINE dims, idim = odim = 80, seed 1234 (run/fastspeech_train.py:17);
+# duration head tuned so random-init durations average ~6.7 frames per phone (~800 frames / 120 phones)
+BENCH_IDIM = 80
+BENCH_ODIM = 80
+BENCH_SEED = 1234
+BENCH_DUR_BIAS = math.log(6.7)
+BENCH_DUR_W_SCALE = 0.2
+
+
+def bench_state_dict() -> Dict[str, np.ndarray]:
+    return synth_state_dict(BENCH_IDIM, BENCH_ODIM, BENCH_SEED, dur_bias=BENCH_DUR_BIAS,
+                            dur_w_scale=BENCH_DUR_W_SCALE, use_scaled_pos_enc=True, **BASELINE_OVERRIDES)
+
+
+def algorithmic_flops(ilens, olens, d=256, U=1024, k=9, Ne=4, Nd=4, Cd=256, Cv=384, kp=3, odim=80) -> float:
+    """Closed form of SURVEY.md §8d (multiply-add = 2 FLOP), summed over utterances."""
+    f = 0.0
+    for tp, tm in zip(ilens, olens):
+        f += Ne * (tp * (8 * d * d + 4 * k * d * U) + 4 * tp * tp * d)
+        f += Nd * (tm * (8 * d * d + 4 * k * d * U) + 4 * tm * tm * d)
+        f += tp * (2 * kp * d * Cd + 2 * kp * Cd * Cd + 2 * Cd)
+        f += 2 * tm * (2 * kp * d * Cv + 2 * kp * Cv * Cv) + 2 * tm * Cv * 5 + 2 * tm * d * 5
+        f += 2 * tm * d * odim
+    return f

@@ -118,7 +118,8 @@ def test_rowdot(nout, C):
     M = 45
     x, W, b = torch.randn(M, C, generator=g), torch.randn(nout, C, generator=g), torch.randn(nout, generator=g)
     out = torch.empty((M, nout), device=DEV)
-    call("fs2_rowdot", ptr(x.to(DEV)), ptr(W.to(DEV)), ptr(b.to(DEV)), ptr(out), M, C, nout, stream())
+    xd, Wd, bd = x.to(DEV), W.to(DEV), b.to(DEV)      # keep the device copies alive across the launch
+    call("fs2_rowdot", ptr(xd), ptr(Wd), ptr(bd), ptr(out), M, C, nout, stream())
     assert (out.cpu() - F.linear(x, W, b)).abs().max().item() <= 1e-4
 
 
@@ -129,7 +130,8 @@ def test_duration_round_matches_oracle():
     logd = torch.cat([torch.tensor(vals), torch.randn(4000, generator=g) * 1.5 + 1.0]).float()
     exp = fs2_oracle.duration_round(logd)
     dur = torch.empty((logd.numel(),), dtype=torch.int32, device=DEV)
-    call("fs2_duration_round", ptr(logd.to(DEV)), ptr(dur), logd.numel(), stream())
+    logd_d = logd.to(DEV)
+    call("fs2_duration_round", ptr(logd_d), ptr(dur), logd.numel(), stream())
     got = dur.cpu().long()
     # the device exp may differ from the host exp in the last ulp: only entries whose exp(x)-1 is
     # within 1e-4 of a .5 boundary may legitimately differ
@@ -176,7 +178,8 @@ def test_length_regulator_bit_exact(control):
     seg = torch.empty((Mf, 2), dtype=torch.int32, device=DEV)
     pos = torch.empty(Mf, dtype=torch.int32, device=DEV)
     lri = torch.empty(Mf, dtype=torch.int32, device=DEV)
-    call("fs2_lr_gather", ptr(hs.to(DEV)), ptr(cum), ptr(cu_d), ptr(cu_f), B, ptr(out), ptr(outb), ptr(seg), ptr(pos),
+    hs_d = hs.to(DEV)
+    call("fs2_lr_gather", ptr(hs_d), ptr(cum), ptr(cu_d), ptr(cu_f), B, ptr(out), ptr(outb), ptr(seg), ptr(pos),
          ptr(lri), Mf, d, hip.BF16, stream())
     assert lri.cpu().tolist() == np.concatenate(exp_idx).tolist()
     exp_rows = torch.cat([hs[cu[b]:cu[b + 1]][torch.from_numpy(exp_idx[b])] for b in range(B)], 0)
@@ -231,7 +234,8 @@ def test_embed_and_variance_add():
     pos = torch.randint(0, 40, (M,), generator=g, dtype=torch.int32)
     pe = fs2_oracle.posenc_table(64, d)
     out = torch.empty((M, d), device=DEV)
-    call("fs2_embed_posenc", ptr(ids.to(DEV)), ptr(pos.to(DEV)), ptr(emb.to(DEV)), ptr(pe.to(DEV)), math.sqrt(d), 1.0,
+    ids_d, pos_d, emb_d, pe_d = ids.to(DEV), pos.to(DEV), emb.to(DEV), pe.to(DEV)
+    call("fs2_embed_posenc", ptr(ids_d), ptr(pos_d), ptr(emb_d), ptr(pe_d), math.sqrt(d), 1.0,
          ptr(out), None, M, d, idim, hip.F32, stream())
     exp = emb[ids] * math.sqrt(d) + pe[pos.long()]
     assert (out.cpu() - exp).abs().max().item() <= 1e-5
@@ -241,8 +245,9 @@ def test_embed_and_variance_add():
     hv = torch.empty((M, d), device=DEV)
     o2 = torch.empty((M, d), device=DEV)
     ob = torch.empty((M, d), device=DEV, dtype=torch.bfloat16)
-    call("fs2_variance_add_posenc", ptr(hs.to(DEV)), ptr(p.to(DEV)), ptr(e.to(DEV)), ptr(Wp.to(DEV)), ptr(bp.to(DEV)),
-         ptr(We.to(DEV)), ptr(be.to(DEV)), 1.0, 1.0, ptr(pe.to(DEV)), ptr(pos.to(DEV)), 1.0, 0.7, ptr(hv), ptr(o2),
+    dv = [t.to(DEV) for t in (hs, p, e, Wp, bp, We, be)]
+    call("fs2_variance_add_posenc", ptr(dv[0]), ptr(dv[1]), ptr(dv[2]), ptr(dv[3]), ptr(dv[4]),
+         ptr(dv[5]), ptr(dv[6]), 1.0, 1.0, ptr(pe_d), ptr(pos_d), 1.0, 0.7, ptr(hv), ptr(o2),
          ptr(ob), M, d, 4, 1, hip.BF16, stream())
     exp_hv = hs + ((e @ We.t() + be) + (p @ Wp.t() + bp))
     assert (hv.cpu() - exp_hv).abs().max().item() <= 1e-5
