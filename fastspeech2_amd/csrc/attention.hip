@@ -19,7 +19,6 @@
 namespace fs2 {
 
 constexpr int AT_THREADS = 256;
-constexpr int AT_BQ = 64;   // queries per workgroup
 constexpr int AT_BK = 64;   // keys per tile
 
 struct AttnArgs {
@@ -30,123 +29,183 @@ struct AttnArgs {
     float scale_log2e;   // log2(e) / sqrt(dk)
 };
 
-template <typename T, int DK>
-__global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnArgs a) {
+typedef __attribute__((address_space(3))) void at_lds_void;
+typedef const __attribute__((address_space(1))) void at_gbl_void;
+
+// K/V tiles (64 keys x DK) live in LDS as unpadded rows whose 16-byte slots are ROTATED by a
+// row-dependent amount (K: rot, V: 2 rot) so that the 16-row fragment reads of K and the
+// 8-row transposed reads of V spread over all bank groups.  The tiles are filled by LDS-DMA
+// (global_load_lds_dwordx4): the LDS side is lane-linear, the rotation is applied to the per-lane
+// SOURCE address.  Two stages: tile t+1 is in flight while tile t is consumed (one barrier per tile).
+template <typename T, int DK, int QT>
+__global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
     typedef typename Frag<T>::type frag_t;
-    constexpr int ROWB = DK * (int)sizeof(T);        // data bytes per K/V row
-    constexpr int STRIDE = ROWB + 16;                // padded LDS row stride
-    constexpr int VPR = ROWB / 16;                   // 16-byte vectors per row
+    constexpr int ROWB = DK * (int)sizeof(T);        // bytes per K/V row
+    constexpr int NS = ROWB / 16;                    // 16-byte slots per row
+    constexpr int TILE_BYTES = AT_BK * ROWB;
+    constexpr int PIECES = TILE_BYTES / 1024;        // 1-KiB DMA pieces per tile
     constexpr int KS = DK / 32;                      // fragment steps over dk
     constexpr int DT = DK / 16;                      // 16-wide dv tiles
-    constexpr int NV = (AT_BK * VPR) / AT_THREADS;   // vectors per thread per tile
-    constexpr int FRAG_BYTES = 8 * (int)sizeof(T);
+    constexpr int RSH = ROWB >= 256 ? 0 : (ROWB == 128 ? 1 : (ROWB == 64 ? 2 : 0));
+    constexpr int EPS = 16 / (int)sizeof(T);         // elements per slot
+    constexpr int BQ = 64 * QT;                      // queries per workgroup
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = smem + AT_BK * STRIDE;
+    // stage s: K image at smem + s * 2 * TILE_BYTES, V image right behind it
 
-    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
     const int r0 = a.cu[b];
     const int len = a.cu[b + 1] - r0;
-    if (qt * AT_BQ >= len) return;
+    if (qblk * BQ >= len) return;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
     const T* __restrict__ base = (const T*)a.qkv + (size_t)r0 * a.ld;
     const int qcol = h * DK, kcol = a.d + h * DK, vcol = 2 * a.d + h * DK;
 
+    auto rot_k = [](int row) { return (row >> RSH) % NS; };
+    auto rot_v = [](int row) { return ((row >> RSH) * 2) % NS; };
+
+    auto stage = [&](int kt, int st) __attribute__((always_inline)) {
+        unsigned char* kdst = smem + st * 2 * TILE_BYTES;
+        unsigned char* vdst = kdst + TILE_BYTES;
+        const int k0 = kt * AT_BK;
+        for (int p = wave; p < PIECES; p += 4) {
+            const int off = p * 1024 + lane * 16;
+            const int row = off / ROWB;
+            const int slot = (off % ROWB) >> 4;
+            int key = k0 + row;
+            key = key < len ? key : len - 1;       // tail keys are masked (-inf); keep the address valid
+            const T* src = base + (size_t)key * a.ld;
+            const int ks_ = (slot + NS - rot_k(row)) % NS;   // slot holds global chunk (slot - rot)
+            const int vs_ = (slot + NS - rot_v(row)) % NS;
+            __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + kcol + ks_ * EPS), (at_lds_void*)(kdst + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + vcol + vs_ * EPS), (at_lds_void*)(vdst + p * 1024), 16, 0, 0);
+        }
+    };
+
     // Q fragments (B operand): Q[q = i][dk = 32 ks + 8 g ..]
-    const int q = qt * AT_BQ + wave * 16 + i;
-    frag_t qf[KS];
+    frag_t qf[QT][KS];
+    int qrow[QT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (q < len)
-            qf[ks] = *(const frag_t*)(base + (size_t)q * a.ld + qcol + ks * 32 + g * 8);
-        else
-            qf[ks] = frag_zero<T>();
+    for (int t = 0; t < QT; ++t) {
+        qrow[t] = qblk * BQ + (wave * QT + t) * 16 + i;
+        const int qc = qrow[t] < len ? qrow[t] : len - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[t][ks] = *(const frag_t*)(base + (size_t)qc * a.ld + qcol + ks * 32 + g * 8);
     }
 
-    f32x4 o[DT];
+    f32x4 o[QT][DT];
+    float m_run[QT], l_part[QT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_part = 0.f;
+    for (int t = 0; t < QT; ++t) {
+        m_run[t] = -INFINITY;
+        l_part[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     const int ntiles = (len + AT_BK - 1) / AT_BK;
+    stage(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();   // tile kt landed (vmcnt(0) + barrier); every wave is done with the other stage
+        if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* Ks = smem + (kt & 1) * 2 * TILE_BYTES;
+        const unsigned char* Vs = Ks + TILE_BYTES;
         const int k0 = kt * AT_BK;
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const int idx = tid + v * AT_THREADS;
-            const int r = idx / VPR, cv = idx % VPR;
-            vec16 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (k0 + r < len) {
-                const T* row = base + (size_t)(k0 + r) * a.ld;
-                kv = *(const vec16*)(row + kcol + cv * (16 / (int)sizeof(T)));
-                vv = *(const vec16*)(row + vcol + cv * (16 / (int)sizeof(T)));
-            }
-            *(vec16*)(Ks + r * STRIDE + cv * 16) = kv;
-            *(vec16*)(Vs + r * STRIDE + cv * 16) = vv;
-        }
-        __syncthreads();
 
-        // ---- S^T tiles: s[nt][r] = score(key = k0 + 16 nt + 4 g + r, query i) ----------------
-        f32x4 s[4];
+        // ---- S^T tiles: s[t][nt][r] = score(key = k0 + 16 nt + 4 g + r, query i of q-tile t) ------
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) s[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = nt * 16 + i;
+            const unsigned char* rowp = Ks + row * ROWB;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const frag_t kf = *(const frag_t*)(Ks + (nt * 16 + i) * STRIDE + ks * 32 * (int)sizeof(T) + g * FRAG_BYTES);
-                s[nt] = mma16(kf, qf[ks], s[nt]);
+                frag_t kf;
+                if constexpr (sizeof(T) == 2) {
+                    kf = *(const frag_t*)(rowp + (((ks * 4 + g) + rot_k(row)) % NS) * 16);
+                } else {
+                    const f32x4 v0 = *(const f32x4*)(rowp + (((ks * 8 + 2 * g) + rot_k(row)) % NS) * 16);
+                    const f32x4 v1 = *(const f32x4*)(rowp + (((ks * 8 + 2 * g + 1) + rot_k(row)) % NS) * 16);
+                    kf = (frag_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][nt] = mma16(kf, qf[t][ks], s[t][nt]);
             }
         }
-        float m_loc = -INFINITY;
+
+        // ---- online softmax, per query (lane-local; the 4 lane groups hold different keys) -------
+        if ((k0 + AT_BK) > len) {     // last tile only: keys beyond the utterance get -inf (exp2 -> exactly 0)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + nt * 16 + 4 * g + r;
-                const float v = key < len ? s[nt][r] * a.scale_log2e : -INFINITY;
-                s[nt][r] = v;
-                m_loc = fmaxf(m_loc, v);
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((k0 + nt * 16 + 4 * g + r) >= len) s[t][nt][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float m_loc = -INFINITY;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = s[t][nt][r] * a.scale_log2e;     // scale > 0: -inf stays -inf
+                    s[t][nt][r] = v;
+                    m_loc = fmaxf(m_loc, v);
+                }
+            m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16, 64));
+            m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
+            const float m_new = fmaxf(m_run[t], m_loc);     // finite: every tile has >= 1 valid key
+            const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);   // v_exp_f32: exp2(-inf) = 0
+            m_run[t] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[t][nt][r] - m_new);
+                    s[t][nt][r] = p;
+                    psum += p;
+                }
+            l_part[t] = l_part[t] * alpha + psum;
+            if (!__all(alpha == 1.0f)) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
             }
-        m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16, 64));
-        m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
-        const float m_new = fmaxf(m_run, m_loc);       // finite: every tile has >= 1 valid key
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[nt][r] - m_new);
-                s[nt][r] = p;
-                psum += p;
-            }
-        l_part = l_part * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T over the two 32-key chunks ---------------------------------------
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            frag_t pf;
+            frag_t pf[QT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pf[r] = from_f32<T>(s[2 * c][r]);
-                pf[4 + r] = from_f32<T>(s[2 * c + 1][r]);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[t][r] = from_f32<T>(s[t][2 * c][r]);
+                    pf[t][4 + r] = from_f32<T>(s[t][2 * c + 1][r]);
+                }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 frag_t vf;
                 if constexpr (sizeof(T) == 2) {
                     // transposed 4x16 block read: lane 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
-                    const unsigned char* p0 = Vs + ((2 * c) * 16 + 4 * g + (i >> 2)) * STRIDE + (dt * 16 + (i & 3) * 4) * 2;
-                    const unsigned char* p1 = p0 + 16 * STRIDE;
+                    const int row0 = (2 * c) * 16 + 4 * g + (i >> 2);
+                    const int row1 = row0 + 16;
+                    const int slot = dt * 2 + ((i & 3) >> 1);
+                    const int sub = (i & 1) * 8;
+                    const unsigned char* p0 = Vs + row0 * ROWB + ((slot + rot_v(row0)) % NS) * 16 + sub;
+                    const unsigned char* p1 = Vs + row1 * ROWB + ((slot + rot_v(row1)) % NS) * 16 + sub;
                     const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
                     const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
 #pragma unroll
@@ -157,30 +216,32 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(AttnArgs a) {
                 } else {
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
-                        const int key = (2 * c + (jj >> 2)) * 16 + 4 * g + (jj & 3);
-                        vf[jj] = *(const T*)(Vs + key * STRIDE + (dt * 16 + i) * (int)sizeof(T));
+                        const int row = (2 * c + (jj >> 2)) * 16 + 4 * g + (jj & 3);
+                        const int col = dt * 16 + i;
+                        vf[jj] = *(const T*)(Vs + row * ROWB + (((col >> 2) + rot_v(row)) % NS) * 16 + (col & 3) * 4);
                     }
                 }
-                o[dt] = mma16(vf, pf, o[dt]);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o[t][dt] = mma16(vf, pf[t], o[t][dt]);
             }
         }
     }
 
-    float l = l_part;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
-    if (q < len) {
-        T* dst = (T*)a.ctx + (size_t)(r0 + q) * a.ldo + h * DK;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            T tmp[4];
+    for (int t = 0; t < QT; ++t) {
+        float l = l_part[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (qrow[t] < len) {
+            T* dst = (T*)a.ctx + (size_t)(r0 + qrow[t]) * a.ldo + h * DK;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tmp[r] = from_f32<T>(o[dt][r] * inv);
-            if constexpr (sizeof(T) == 2)
-                *(uint2*)(dst + dt * 16 + 4 * g) = *(const uint2*)tmp;
-            else
-                *(f32x4*)(dst + dt * 16 + 4 * g) = *(const f32x4*)tmp;
+            for (int dt = 0; dt < DT; ++dt) {
+                f32x4 v = o[t][dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= inv;
+                store4<T>(dst + dt * 16 + 4 * g, v);
+            }
         }
     }
 }
@@ -218,14 +279,15 @@ __global__ __launch_bounds__(256) void attention_dump_kernel(const T* __restrict
 
 template <typename T, int DK>
 static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStream_t stream) {
-    constexpr int lds = 2 * AT_BK * (DK * (int)sizeof(T) + 16);
+    constexpr int QT = sizeof(T) == 2 ? 2 : 1;     // 32 (bf16) / 16 (f32) queries per wave
+    constexpr int lds = 2 * 2 * AT_BK * DK * (int)sizeof(T);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attention_kernel<T, DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attention_kernel<T, DK, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    dim3 grid((max_len + AT_BQ - 1) / AT_BQ, H, B);
-    hipLaunchKernelGGL((attention_kernel<T, DK>), grid, dim3(AT_THREADS), lds, stream, a);
+    dim3 grid((max_len + 64 * QT - 1) / (64 * QT), H, B);
+    hipLaunchKernelGGL((attention_kernel<T, DK, QT>), grid, dim3(AT_THREADS), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_attention");
     return FS2_OK;
 }

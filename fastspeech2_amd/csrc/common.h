@@ -49,6 +49,17 @@ template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_zer
     return z;
 }
 
+// store 4 consecutive elements (8-byte bf16 / 16-byte f32 access)
+template <typename T> __device__ __forceinline__ void store4(T* dst, const f32x4& v) {
+    T t4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t4[r] = from_f32<T>(v[r]);
+    if constexpr (sizeof(T) == 2)
+        *(uint2*)dst = *(const uint2*)t4;
+    else
+        *(f32x4*)dst = *(const f32x4*)t4;
+}
+
 // 16-byte vector copy helpers
 struct __attribute__((aligned(16))) vec16 { uint32_t x, y, z, w; };
 

@@ -50,10 +50,7 @@ __global__ void embed_posenc_kernel(const long long* __restrict__ ids, const int
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = e[r] * xscale + alpha * p[r];
     if (out_f32) *(f32x4*)(out_f32 + (size_t)m * d + c) = v;
-    if (out_t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out_t[(size_t)m * d + c + r] = from_f32<T>(v[r]);
-    }
+    if (out_t) store4<T>(out_t + (size_t)m * d + c, v);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -105,11 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
             if (out_f32) *(f32x4*)(out_f32 + (size_t)row * C + j * 4) = o;
-            if (out_t) {
-                T* ot = out_t + (size_t)row * C + j * 4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ot[r] = from_f32<T>(o[r]);
-            }
+            if (out_t) store4<T>(out_t + (size_t)row * C + j * 4, o);
         }
     }
 }
@@ -165,66 +158,59 @@ __global__ void duration_round_kernel(const float* __restrict__ logd, int* __res
 // (D9, :28-30), inclusive scan; then utterance offsets.  One workgroup; the whole problem is
 // a few thousand integers.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lr_plan_kernel(const int* __restrict__ dur_in, const int* __restrict__ cu_phone,
-                                                      float control, int apply_control, int* __restrict__ dur_out,
-                                                      int* __restrict__ cum, int* __restrict__ olens,
-                                                      int* __restrict__ cu_frames, int B) {
-    __shared__ int sh[256];
-    __shared__ int carry_sh;
-    const int tid = threadIdx.x;
-    int frames_before = 0;
-    for (int b = 0; b < B; ++b) {
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ int wave_iscan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void lr_plan_kernel(const int* __restrict__ dur_in, const int* __restrict__ cu_phone,
+                                                       float control, int apply_control, int* __restrict__ dur_out,
+                                                       int* __restrict__ cum, int* __restrict__ olens,
+                                                       int* __restrict__ cu_frames, int B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int b = wave; b < B; b += nwaves) {          // one wave per utterance
         const int p0 = cu_phone[b], p1 = cu_phone[b + 1];
-        // pass 1: scaled durations + their sum
         int local = 0;
-        for (int p = p0 + tid; p < p1; p += 256) {
+        for (int p = p0 + lane; p < p1; p += 64) {
             int dv = dur_in[p];
             if (apply_control) dv = (int)rintf((float)dv * control);
             dur_out[p] = dv;
             local += dv;
         }
-        sh[tid] = local;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) sh[tid] += sh[tid + o];
-            __syncthreads();
-        }
-        const int total = sh[0];
-        __syncthreads();
-        const bool all_zero = (total == 0);
-        // pass 2: inclusive scan in chunks of 256 with a running carry
-        if (tid == 0) carry_sh = 0;
-        __syncthreads();
-        for (int base = p0; base < p1; base += 256) {
-            const int p = base + tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+        const bool all_zero = (local == 0);
+        int carry = 0;
+        for (int base = p0; base < p1; base += 64) {
+            const int p = base + lane;
             int dv = 0;
             if (p < p1) {
                 dv = all_zero ? 1 : dur_out[p];
                 if (all_zero) dur_out[p] = 1;
             }
-            sh[tid] = dv;
-            __syncthreads();
-            for (int o = 1; o < 256; o <<= 1) {
-                const int t = (tid >= o) ? sh[tid - o] : 0;
-                __syncthreads();
-                sh[tid] += t;
-                __syncthreads();
-            }
-            const int carry = carry_sh;
-            if (p < p1) cum[p] = carry + sh[tid];
-            __syncthreads();
-            if (tid == 255) carry_sh = carry + sh[255];
-            __syncthreads();
+            const int sc = wave_iscan(dv, lane);
+            if (p < p1) cum[p] = carry + sc;
+            carry += __shfl(sc, 63, 64);
         }
-        const int olen = all_zero ? (p1 - p0) : total;
-        if (tid == 0) {
-            olens[b] = olen;
-            cu_frames[b] = frames_before;
-        }
-        frames_before += olen;
-        __syncthreads();
+        if (lane == 0) olens[b] = all_zero ? (p1 - p0) : local;
     }
-    if (tid == 0) cu_frames[B] = frames_before;
+    __syncthreads();   // olens written by this block's waves are visible block-wide after the barrier
+    if (wave == 0) {
+        int carry = 0;
+        for (int base = 0; base < B; base += 64) {
+            const int b = base + lane;
+            const int v = b < B ? olens[b] : 0;
+            const int sc = wave_iscan(v, lane);
+            if (b < B) cu_frames[b] = carry + sc - v;
+            carry += __shfl(sc, 63, 64);
+        }
+        if (lane == 0) cu_frames[B] = carry;
+    }
 }
 
 // gather: frame t of utterance b copies phone j = #{ p : cum_b[p] <= t } (zero-duration phones
@@ -259,11 +245,7 @@ __global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict_
     for (int k = lane; k < dv; k += 64) {
         const f32x4 v = *(const f32x4*)(src + k * 4);
         if (out_f32) *(f32x4*)(out_f32 + (size_t)row * d + k * 4) = v;
-        if (out_t) {
-            T* o = out_t + (size_t)row * d + k * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
-        }
+        if (out_t) store4<T>(out_t + (size_t)row * d + k * 4, v);
     }
 }
 
@@ -286,21 +268,49 @@ __global__ void variance_add_posenc_kernel(const float* __restrict__ hs, const f
     const int m = (int)(idx / dv), c = (int)(idx % dv) * 4;
     const f32x4 h = *(const f32x4*)(hs + (size_t)m * d + c);
     const f32x4 pp = *(const f32x4*)(pe + (size_t)pos[m] * d + c);
-    f32x4 v;
+    const f32x4 bpv = *(const f32x4*)(bp + c);
+    const f32x4 bev = *(const f32x4*)(be + c);
+    f32x4 pemb = bpv, eemb = bev;
+    if (pdim == 4 && edim == 1) {          // the model's shapes (network/fastspeech2.py:135-136)
+        f32x4 pv = *(const f32x4*)(pitch + (size_t)m * 4);
+        const float ev = energy[m] * escale;
+        const f32x4 wev = *(const f32x4*)(We + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 w = *(const f32x4*)(Wp + (size_t)(c + r) * 4);
+            float t = bpv[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += w[j] * (pv[j] * pscale);
+            pemb[r] = t;
+            eemb[r] = bev[r] + wev[r] * ev;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = bpv[r];
+            for (int j = 0; j < pdim; ++j) t += Wp[(c + r) * pdim + j] * (pitch[(size_t)m * pdim + j] * pscale);
+            pemb[r] = t;
+            float u = bev[r];
+            for (int j = 0; j < edim; ++j) u += We[(c + r) * edim + j] * (energy[(size_t)m * edim + j] * escale);
+            eemb[r] = u;
+        }
+    }
+    f32x4 x, v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float pemb = bp[c + r];
-        for (int j = 0; j < pdim; ++j) pemb += Wp[(c + r) * pdim + j] * (pitch[(size_t)m * pdim + j] * pscale);
-        float eemb = be[c + r];
-        for (int j = 0; j < edim; ++j) eemb += We[(c + r) * edim + j] * (energy[(size_t)m * edim + j] * escale);
-        const float x = h[r] + (eemb + pemb);
-        if (hs_va) hs_va[(size_t)m * d + c + r] = x;
-        v[r] = x * xscale + alpha * pp[r];
+        x[r] = h[r] + (eemb[r] + pemb[r]);
+        v[r] = x[r] * xscale + alpha * pp[r];
     }
+    if (hs_va) *(f32x4*)(hs_va + (size_t)m * d + c) = x;
     if (out_f32) *(f32x4*)(out_f32 + (size_t)m * d + c) = v;
     if (out_t) {
+        T t4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out_t[(size_t)m * d + c + r] = from_f32<T>(v[r]);
+        for (int r = 0; r < 4; ++r) t4[r] = from_f32<T>(v[r]);
+        if constexpr (sizeof(T) == 2)
+            *(uint2*)(out_t + (size_t)m * d + c) = *(const uint2*)t4;
+        else
+            *(f32x4*)(out_t + (size_t)m * d + c) = *(const f32x4*)t4;
     }
 }
 
@@ -402,7 +412,7 @@ extern "C" int fs2_duration_round(const float* logd, int* dur, int M, hipStream_
 extern "C" int fs2_lr_plan(const int* dur_in, const int* cu_phone, float control, int* dur_out, int* cum, int* olens,
                            int* cu_frames, int B, hipStream_t stream) {
     FS2_CHECK_ARG(dur_in && cu_phone && dur_out && cum && olens && cu_frames && B > 0, "fs2_lr_plan: bad args");
-    hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(256), 0, stream, dur_in, cu_phone, control,
+    hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(1024), 0, stream, dur_in, cu_phone, control,
                        control != 1.0f ? 1 : 0, dur_out, cum, olens, cu_frames, B);
     FS2_CHECK_LAUNCH("fs2_lr_plan");
     return FS2_OK;
