@@ -23,6 +23,7 @@
 // permuted order so that a lane ends up with 16 CONSECUTIVE output channels of one token:
 // 64-byte (f32) / 32-byte (bf16) contiguous epilogue accesses.
 #include "common.h"
+#include <stdlib.h>
 
 namespace fs2 {
 
@@ -42,6 +43,8 @@ struct ConvGemmArgs {
     int ldx, ldr, ldo;
     int relu, out_f32;
     int n_tiles;
+    int ksplit;               // split of the channel-chunk range over gridDim.y partial outputs
+    long long split_stride;   // elements between two partial outputs
 };
 
 // 16-byte slot swizzles (see header comment)
@@ -55,8 +58,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
     __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int MT, int NT, bool DMA>
-__global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a) {
+template <typename T, int MT, int NT, bool DMA, bool XDB>
+__global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(ConvGemmArgs a) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
     constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte slot
     constexpr int BKE = CG_ROWB / (int)sizeof(T);   // channels per chunk (64 bf16 / 32 f32)
@@ -66,10 +69,11 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
     constexpr int W_BYTES = BN * CG_ROWB;
     constexpr int X_INSTR = XROWS / 8;              // 1-KiB (8-row) pieces of the X image
     constexpr int W_INSTR = BN / 8;
+    constexpr int XBUFS = XDB ? 2 : 1;            // X image single-buffered: 3 workgroups per CU fit in LDS
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [X buf0][X buf1][W buf0][W buf1]
+    // [X buf0]([X buf1])[W buf0][W buf1]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,8 +88,13 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
     const int m0 = m_tile * BM;
     const int n0 = n_tile * BN;
     const int pad = (a.taps - 1) >> 1;
-    const int nchunks = (a.Cin + BKE - 1) / BKE;
-    const int nsteps = nchunks * a.taps;
+    // split-K: workgroup y handles channel chunks [chunk_lo, chunk_hi) and writes partial output y
+    const int nchunks_all = (a.Cin + BKE - 1) / BKE;
+    const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
+    const int chunk_lo = blockIdx.y * cps;
+    const int chunk_hi = min(nchunks_all, chunk_lo + cps);
+    const int nsteps = max(chunk_hi - chunk_lo, 0) * a.taps;
+    const float* bias = blockIdx.y == 0 ? a.bias : nullptr;
 
     const T* __restrict__ X = (const T*)a.X;
     const T* __restrict__ W = (const T*)a.W;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
         }
     };
     auto stage_w = [&](int tap, int chunk, int buf) __attribute__((always_inline)) {
-        unsigned char* dst = smem + 2 * X_BYTES + buf * W_BYTES;
+        unsigned char* dst = smem + XBUFS * X_BYTES + buf * W_BYTES;
         const int c0 = chunk * BKE;
         const T* wt = W + (size_t)tap * a.N * a.Cin;
 #pragma unroll
@@ -165,12 +174,14 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
     const int wrow_base = wn * (16 * NT) + (i >> 2) * (4 * NT) + (i & 3);
     const int xrow_base = wm * (16 * MT) + i;
 
-    stage_x(0, 0);
-    stage_w(0, 0, 0);
+    if (nsteps > 0) {
+        stage_x(chunk_lo, 0);
+        stage_w(0, chunk_lo, 0);
+    }
     __syncthreads();
 
     int xcur = 0, wcur = 0;
-    int tap = 0, chunk = 0;
+    int tap = 0, chunk = chunk_lo;
     for (int step = 0; step < nsteps; ++step) {
         int ntap = tap + 1, nchunk = chunk;
         if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
@@ -178,11 +189,11 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
         const bool next_x = has_next && (ntap == 0);
         if (DMA) {   // LDS-DMA prefetch of step+1 into the other buffers, in flight during the MFMAs
             if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
-            if (next_x) stage_x(nchunk, xcur ^ 1);
+            if (XDB && next_x) stage_x(nchunk, xcur ^ 1);
         }
 
         const unsigned char* xs = smem + xcur * X_BYTES;
-        const unsigned char* ws = smem + 2 * X_BYTES + wcur * W_BYTES;
+        const unsigned char* ws = smem + XBUFS * X_BYTES + wcur * W_BYTES;
         const int shift = tap - pad;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -224,11 +235,15 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
 
         if (!DMA) {  // generic path: synchronous register staging of step+1 (odd shapes only)
             if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
-            if (next_x) stage_x(nchunk, xcur ^ 1);
+            if (XDB && next_x) stage_x(nchunk, xcur ^ 1);
         }
         __syncthreads();   // also drains the LDS-DMA (vmcnt(0)) issued at the top of this step
+        if (!XDB && next_x) {   // single X image: refill it once per channel chunk, between two barriers
+            stage_x(nchunk, 0);
+            __syncthreads();
+        }
         wcur ^= 1;
-        if (next_x) xcur ^= 1;
+        if (XDB && next_x) xcur ^= 1;
         tap = ntap;
         chunk = nchunk;
     }
@@ -248,9 +263,9 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
             ncl[nt] = nok[nt] ? nb + 4 * nt : 0;
             bv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if (a.bias) {
+        if (bias) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4*)(a.bias + ncl[nt]);
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const f32x4*)(bias + ncl[nt]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -274,12 +289,12 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
                 for (int nt = 0; nt < NT; ++nt) v[nt] += rv[nt];
             }
             if (a.out_f32) {
-                float* o = (float*)a.out + mc * a.ldo;
+                float* o = (float*)a.out + (size_t)blockIdx.y * a.split_stride + mc * a.ldo;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     if (mok && nok[nt]) *(f32x4*)(o + ncl[nt]) = v[nt];
             } else {
-                T* o = (T*)a.out + mc * a.ldo;
+                T* o = (T*)a.out + (size_t)blockIdx.y * a.split_stride + mc * a.ldo;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     T t4[4];
@@ -306,31 +321,32 @@ __global__ __launch_bounds__(CG_THREADS, 2) void conv_gemm_kernel(ConvGemmArgs a
                     const int n = nb + 4 * nt + r;
                     if (n >= a.N) continue;
                     float s = acc[mt][nt][r];
-                    if (a.bias) s += a.bias[n];
+                    if (bias) s += bias[n];
                     if (a.relu) s = fmaxf(s, 0.f);
                     if (a.res) s += a.res[(size_t)m * a.ldr + n];
+                    const size_t oidx = (size_t)blockIdx.y * a.split_stride + (size_t)m * a.ldo + n;
                     if (a.out_f32)
-                        ((float*)a.out)[(size_t)m * a.ldo + n] = s;
+                        ((float*)a.out)[oidx] = s;
                     else
-                        ((T*)a.out)[(size_t)m * a.ldo + n] = from_f32<T>(s);
+                        ((T*)a.out)[oidx] = from_f32<T>(s);
                 }
         }
     }
 }
 
-template <typename T, int MT, int NT, bool DMA>
+template <typename T, int MT, int NT, bool DMA, bool XDB>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 32 * MT, BN = 32 * NT;
-    constexpr int lds = 2 * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
+    constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, DMA>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, DMA, XDB>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     a.n_tiles = (a.N + BN - 1) / BN;
     const int m_tiles = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, DMA>), dim3(a.n_tiles * m_tiles), dim3(CG_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, DMA, XDB>), dim3(a.n_tiles * m_tiles, a.ksplit), dim3(CG_THREADS), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_conv_gemm");
     return FS2_OK;
 }
@@ -339,10 +355,13 @@ template <typename T>
 static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     constexpr int BKE = CG_ROWB / (int)sizeof(T);
     const bool dma = (a.Cin % BKE) == 0;
-    const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const bool small = big_blocks < 384;   // would leave most of the 256 CUs idle: use 64x64 tiles
-    if (dma) return small ? launch_conv_gemm<T, 2, 2, true>(a, stream) : launch_conv_gemm<T, 4, 4, true>(a, stream);
-    return small ? launch_conv_gemm<T, 2, 2, false>(a, stream) : launch_conv_gemm<T, 4, 4, false>(a, stream);
+    const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
+    const bool small = big_blocks < 200;   // would leave most of the 256 CUs idle: use 64x64 tiles
+    if (dma) {
+        if (small) return launch_conv_gemm<T, 2, 2, true, true>(a, stream);
+        return launch_conv_gemm<T, 4, 4, true, false>(a, stream);
+    }
+    return small ? launch_conv_gemm<T, 2, 2, false, true>(a, stream) : launch_conv_gemm<T, 4, 4, false, true>(a, stream);
 }
 
 }  // namespace fs2
@@ -350,7 +369,8 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 // dtype: 0 = f32, 1 = bf16 (include/fs2_hip.h)
 extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out,
                              const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
-                             int relu, int out_f32, int dtype, hipStream_t stream) {
+                             int relu, int out_f32, int dtype, int ksplit, long long split_stride,
+                             hipStream_t stream) {
     using namespace fs2;
     FS2_CHECK_ARG(X && W && out, "fs2_conv_gemm: null X/W/out");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0, "fs2_conv_gemm: bad dims M=%d N=%d Cin=%d", M, N, Cin);
@@ -365,10 +385,14 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
     FS2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)out & 15) == 0 &&
                       ((uintptr_t)bias & 15) == 0 && ((uintptr_t)res & 15) == 0,
                   "fs2_conv_gemm: pointers must be 16-byte aligned");
+    FS2_CHECK_ARG(ksplit >= 1 && ksplit <= 16, "fs2_conv_gemm: ksplit=%d (1..16)", ksplit);
+    FS2_CHECK_ARG(ksplit == 1 || (!relu && !res && split_stride >= (long long)M * ldo && split_stride % 4 == 0),
+                  "fs2_conv_gemm: split-K partial outputs take no relu / residual and need split_stride >= M*ldo");
     if (M == 0) return FS2_OK;
     ConvGemmArgs a;
     a.X = X; a.W = W; a.bias = bias; a.res = res; a.out = out; a.seg = (const int2*)seg;
     a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.ldx = ldx; a.ldr = ldr; a.ldo = ldo;
     a.relu = relu; a.out_f32 = out_f32; a.n_tiles = 1;
+    a.ksplit = ksplit; a.split_stride = ksplit > 1 ? split_stride : 0;
     return dtype == 0 ? dispatch_conv_gemm<float>(a, stream) : dispatch_conv_gemm<bf16_t>(a, stream);
 }

@@ -59,25 +59,34 @@ __global__ void embed_posenc_kernel(const long long* __restrict__ ids, const int
 // ---------------------------------------------------------------------------------------
 constexpr int LN_MAXV = 4;  // float4 per lane -> C <= 1024
 
+// y = x + sum_p parts[p]  (residual add of GEMM outputs, incl. split-K partials; x may be null),
+// optionally stored (sum_out, may alias x), then LayerNorm(y) -> fp32 and/or T copies.
+// (network/encoder.py:178-187: `residual + sublayer(x)` followed / preceded by norm1 / norm2)
 template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float* __restrict__ out_f32,
-                                                        T* __restrict__ out_t, int M, int C, float eps) {
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ parts,
+                                                            int nparts, long long part_stride,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* sum_out, float* out_f32, T* __restrict__ out_t,
+                                                            int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
     const int cv = C >> 2;
-    const float* xr = x + (size_t)row * C;
+    const size_t roff = (size_t)row * C;
     f32x4 v[LN_MAXV];
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
         const int j = lane + k * 64;
         if (j < cv) {
-            v[k] = *(const f32x4*)(xr + j * 4);
-            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+            f32x4 t = x ? *(const f32x4*)(x + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+            v[k] = t;
+            if (sum_out) *(f32x4*)(sum_out + roff + j * 4) = t;
+            s += (t[0] + t[1]) + (t[2] + t[3]);
         }
     }
+    if (!w) return;   // sum only
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -101,8 +110,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
-            if (out_f32) *(f32x4*)(out_f32 + (size_t)row * C + j * 4) = o;
-            if (out_t) store4<T>(out_t + (size_t)row * C + j * 4, o);
+            if (out_f32) *(f32x4*)(out_f32 + roff + j * 4) = o;
+            if (out_t) store4<T>(out_t + roff + j * 4, o);
         }
     }
 }
@@ -375,20 +384,30 @@ extern "C" int fs2_embed_posenc(const long long* ids, const int* pos, const floa
     return FS2_OK;
 }
 
+extern "C" int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
+                                 const float* b, float* sum_out, float* out_f32, void* out_t, int M, int C, float eps,
+                                 int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG((x || nparts > 0) && (nparts == 0 || parts), "fs2_add_layernorm: no input");
+    FS2_CHECK_ARG((w && b && (out_f32 || out_t)) || (!w && sum_out), "fs2_add_layernorm: nothing to write");
+    FS2_CHECK_ARG(nparts >= 0 && nparts <= 16 && (nparts <= 1 || part_stride >= (long long)M * C),
+                  "fs2_add_layernorm: bad partial layout");
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "fs2_add_layernorm: C=%d unsupported (multiple of 4, <= %d)",
+                  C, 256 * LN_MAXV);
+    if (M <= 0) return FS2_OK;
+    if (dtype == 1)
+        hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
+                           part_stride, w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps);
+    else
+        hipLaunchKernelGGL(add_layernorm_kernel<float>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
+                           part_stride, w, b, sum_out, out_f32, (float*)out_t, M, C, eps);
+    FS2_CHECK_LAUNCH("fs2_add_layernorm");
+    return FS2_OK;
+}
+
 extern "C" int fs2_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_t, int M, int C,
                              float eps, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(x && w && b && (out_f32 || out_t), "fs2_layernorm: null pointer");
-    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "fs2_layernorm: C=%d unsupported (multiple of 4, <= %d)", C,
-                  256 * LN_MAXV);
-    if (M <= 0) return FS2_OK;
-    if (dtype == 1)
-        hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, out_f32,
-                           (bf16_t*)out_t, M, C, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, out_f32,
-                           (float*)out_t, M, C, eps);
-    FS2_CHECK_LAUNCH("fs2_layernorm");
-    return FS2_OK;
+    return fs2_add_layernorm(x, nullptr, 0, 0, w, b, nullptr, out_f32, out_t, M, C, eps, dtype, stream);
 }
 
 extern "C" int fs2_rowdot(const float* x, const float* W, const float* b, float* out, int M, int C, int nout,

@@ -161,31 +161,59 @@ class Engine:
     def _empty(self, shape, code=None, dtype=None):
         return torch.empty(shape, device=self.dev, dtype=dtype or hip.TORCH_DTYPE[code])
 
-    def _gemm(self, x, w, bias, M, N, Cin, taps, code, seg=None, res=None, relu=False, out_f32=False, tag=None):
-        out = self._empty((M, N), dtype=torch.float32 if out_f32 else hip.TORCH_DTYPE[code])
+    @staticmethod
+    def _ksplit(M, N, Cin, taps, code):
+        """Split-K factor for a GEMM whose 128x128 tiling would leave most CUs idle (phone-level
+        stacks, batch-1 decoding).  Only used where an add+LayerNorm kernel consumes the partials."""
+        nch = -(-Cin // (64 if code == BF16 else 32))
+        blocks = -(-M // 128) * -(-N // 128)
+        if blocks >= 200 or nch * taps < 32:
+            return 1
+        ks = max(1, min(nch, 8, 256 // blocks))
+        while ks > 1 and (nch // ks) * taps < 8:
+            ks -= 1
+        return ks
+
+    def _gemm(self, x, w, bias, M, N, Cin, taps, code, seg=None, res=None, relu=False, out_f32=False, tag=None,
+              ksplit=1, out=None):
+        if out is None:
+            shape = (ksplit, M, N) if ksplit > 1 else (M, N)
+            out = self._empty(shape, dtype=torch.float32 if out_f32 else hip.TORCH_DTYPE[code])
         prof = self.profile is not None and tag is not None
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps,
-             Cin, N, N, int(relu), int(out_f32), code, stream())
+             Cin, N, N, int(relu), int(out_f32), code, ksplit, M * N, stream())
         if prof:
             e1.record()
             self.profile.append((tag, M, N, Cin * taps, e0, e1))
         return out
 
-    def _ln(self, x, w, b, M, C, code, want_f32, want_t):
+    def _ln(self, x, w, b, M, C, code, want_f32, want_t, parts=None, sum_out=None):
+        """LayerNorm(x + sum(parts)); parts: fp32 [nparts, M, C] GEMM outputs (or None).  Returns
+        (fp32 copy or None, T copy or None).  sum_out (may be x) receives x + sum(parts)."""
         of = self._empty((M, C), dtype=torch.float32) if (want_f32 or (want_t and code == F32)) else None
         ot = self._empty((M, C), code) if (want_t and code != F32) else None
-        call("fs2_layernorm", ptr(x), ptr(w), ptr(b), ptr(of), ptr(ot), M, C, LN_EPS, code, stream())
+        nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
+        call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
+             M, C, LN_EPS, code, stream())
         return of, (of if code == F32 else ot)
 
     # ------------------------------------------------------------------ FFT stack
     def _run_stack(self, st: _Stack, x32, xt, seg, cu_dev, B, max_len, M, attn_dump=None, lens=None):
+        """EncoderLayer.forward x N (network/encoder.py:168-189).  Sub-layer outputs stay as raw fp32
+        GEMM outputs (`pend`, possibly split-K partials); the residual add is done by the LayerNorm
+        kernel that needs the sum next (norm1 / norm2 / after_norm)."""
         d, code = self.d, st.code
+        pend = None                       # GEMM output(s) not yet added to the residual stream x32
         for li, L in enumerate(st.layers):
-            # ---- self-attention sub-layer (network/encoder.py:171-180)
-            a_t = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, False, True)[1] if st.pre_ln else xt
+            # ---- self-attention sub-layer (:171-180)
+            if st.pre_ln:
+                a_t = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
+                pend = None
+            else:
+                a_t = xt
             qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code)
             if attn_dump is not None:
                 attn_dump.append(self._dump_attention(qkv, lens, code))
@@ -194,26 +222,28 @@ class Engine:
                  stream())
             if st.concat_after:
                 att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
-                y = self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, res=x32, out_f32=True)
-                y = self._gemm(att, L["wc_a"], None, M, d, d, 1, code, res=y, out_f32=True)
+                pend = self._empty((2, M, d), dtype=torch.float32)
+                self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, out_f32=True, out=pend[0])
+                self._gemm(att, L["wc_a"], None, M, d, d, 1, code, out_f32=True, out=pend[1])
             else:
-                y = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, res=x32, out_f32=True)
-            if st.pre_ln:
-                x32 = y
-            else:
-                x32, xt = self._ln(y, L["norm1_w"], L["norm1_b"], M, d, code, True, True)
+                pend = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, out_f32=True,
+                                  ksplit=self._ksplit(M, d, d, 1, code))
             # ---- position-wise feed-forward sub-layer (:182-187)
-            f_t = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, False, True)[1] if st.pre_ln else xt
+            if st.pre_ln:
+                f_t = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
+            else:
+                x32, xt = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, True, True, parts=pend)
+                f_t = xt
             taps, U = L["taps"], L["units"]
             sg = seg if taps > 1 else None
             hdn = self._gemm(f_t, L["w1"], L["b1"], M, U, d, taps, code, seg=sg, relu=True, tag="ffn1")
-            y = self._gemm(hdn, L["w2"], L["b2"], M, d, U, taps, code, seg=sg, res=x32, out_f32=True, tag="ffn2")
-            if st.pre_ln:
-                x32 = y
-            else:
-                x32, xt = self._ln(y, L["norm2_w"], L["norm2_b"], M, d, code, True, True)
+            pend = self._gemm(hdn, L["w2"], L["b2"], M, d, U, taps, code, seg=sg, out_f32=True, tag="ffn2",
+                              ksplit=self._ksplit(M, d, U, taps, code))
+            if not st.pre_ln:
+                x32, xt = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, True, True, parts=pend)
+                pend = None
         if st.pre_ln:
-            x32, xt = self._ln(x32, st.after_w, st.after_b, M, d, code, True, True)
+            x32, xt = self._ln(x32, st.after_w, st.after_b, M, d, code, True, True, parts=pend)
         return x32, xt
 
     def _dump_attention(self, qkv, lens, code):

@@ -28,7 +28,8 @@ _SIGNATURES = {
     "fs2_build_seg": [_P, _I, _P, _P, _I, _P],
     "fs2_embed_posenc": [_P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P],
     "fs2_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
-    "fs2_conv_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_conv_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "fs2_add_layernorm": [_P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fs2_attention_dump": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "fs2_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -54,6 +54,14 @@ int fs2_embed_posenc(const long long* ids, const int* pos, const float* emb, con
 int fs2_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_t, int M, int C,
                   float eps, int dtype, hipStream_t stream);
 
+/* y = x + sum_p parts[p] (x fp32 [M,C] or NULL; parts fp32 [nparts][part_stride], the outputs of
+ * fs2_conv_gemm incl. split-K partials), optionally stored to sum_out (may alias x); then LayerNorm(y)
+ * when w != NULL.  The `residual + sublayer(x)` adds of EncoderLayer.forward fused with norm1 / norm2 /
+ * after_norm (network/encoder.py:171-187, :252-253). */
+int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
+                      const float* b, float* sum_out, float* out_f32, void* out_t, int M, int C, float eps,
+                      int dtype, hipStream_t stream);
+
 /* Conv1d over time ("same" zero padding inside each utterance) or Linear (taps == 1) as an MFMA
  * implicit GEMM:  out = [relu](sum_tap X[m+tap-pad,:] . W[tap]^T + bias) [+ res]
  * X [M,ldx] T; W packed [taps][N][Cin] T; bias fp32 [N] or NULL; res fp32 [M,ldr] or NULL;
@@ -63,7 +71,7 @@ int fs2_layernorm(const float* x, const float* w, const float* b, float* out_f32
  * feat_out (network/encoder.py:39-44, :57-60, :89; network/fastspeech2.py:158-159, :219). */
 int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out, const int* seg,
                   int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int out_f32, int dtype,
-                  hipStream_t stream);
+                  int ksplit, long long split_stride, hipStream_t stream);
 
 /* Fused varlen multi-head self-attention (scores, softmax, P.V) over packed qkv [M, ld] T laid out
  * q | k | v with each part [n_heads][dk]; ctx [M, ldo] T.  dk in {32, 64, 96, 128}.

@@ -80,7 +80,7 @@ def test_conv_gemm(dtype, taps, cin, n, lens):
     for relu, use_res, out_f32 in [(False, False, True), (True, False, False), (False, True, True)]:
         out = torch.empty((M, n), device=DEV, dtype=torch.float32 if out_f32 else tdt)
         call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), ptr(rd) if use_res else None, ptr(out),
-             ptr(seg) if taps > 1 else None, M, n, cin, taps, cin, n, n, int(relu), int(out_f32), code, stream())
+             ptr(seg) if taps > 1 else None, M, n, cin, taps, cin, n, n, int(relu), int(out_f32), code, 1, 0, stream())
         exp = ref.clone()
         if relu:
             exp = exp.clamp_min(0)
@@ -90,6 +90,45 @@ def test_conv_gemm(dtype, taps, cin, n, lens):
         t = tol if out_f32 or dtype == "fp32" else 1e-2   # + output rounding to bf16
         err = (got - exp).abs().max().item()
         assert err <= t * max(1.0, exp.abs().max().item()), (relu, use_res, out_f32, err)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("taps,cin,n,lens,ksplit", [(9, 1024, 256, [150, 140], 4), (1, 256, 256, [77], 3),
+                                                    (3, 96, 64, [30, 9], 2)])
+def test_conv_gemm_splitk_then_add_layernorm(dtype, taps, cin, n, lens, ksplit):
+    """split-K partial outputs + the residual/LayerNorm kernel that sums them (post-LN block tail:
+    LN(x + conv(h)), network/encoder.py:185-187)."""
+    code = hip.DTYPE_CODE[dtype]
+    tdt = hip.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(7 + taps + cin)
+    M = sum(lens)
+    x = torch.randn(M, cin, generator=g)
+    w = torch.randn(n, cin, taps, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(n, generator=g) * 0.1
+    res = torch.randn(M, n, generator=g)
+    lw, lb = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    xq, wq = x.to(tdt).float(), w.to(tdt).float()
+    outs, r0 = [], 0
+    for L in lens:
+        xi = xq[r0:r0 + L].t().unsqueeze(0)
+        outs.append(F.conv1d(xi.double(), wq.double(), b.double(), padding=(taps - 1) // 2).squeeze(0).t())
+        r0 += L
+    y = res.double() + torch.cat(outs, 0)
+    ref = F.layer_norm(y, (n,), lw.double(), lb.double(), 1e-12)
+    _, _, seg, _ = _seg_tables(lens)
+    xd, wd = x.to(DEV, tdt).contiguous(), w.permute(2, 0, 1).to(DEV, tdt).contiguous()
+    bd, rd, lwd, lbd = b.to(DEV), res.to(DEV), lw.to(DEV), lb.to(DEV)
+    parts = torch.full((ksplit, M, n), float("nan"), device=DEV)
+    call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), None, ptr(parts), ptr(seg) if taps > 1 else None, M, n, cin, taps,
+         cin, n, n, 0, 1, code, ksplit, M * n, stream())
+    o32 = torch.empty((M, n), device=DEV)
+    ot = torch.empty((M, n), device=DEV, dtype=tdt)
+    call("fs2_add_layernorm", ptr(rd), ptr(parts), ksplit, M * n, ptr(lwd), ptr(lbd), ptr(rd), ptr(o32), ptr(ot), M, n,
+         1e-12, code, stream())
+    tol = 1e-4 if dtype == "fp32" else 5e-3
+    assert (rd.cpu().double() - y).abs().max().item() <= tol * max(1.0, y.abs().max().item())     # sum_out (in place)
+    assert (o32.cpu().double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert (ot.float().cpu().double() - ref).abs().max().item() <= (tol if dtype == "fp32" else 5e-2)
 
 
 @pytest.mark.parametrize("C", [64, 256, 384, 1024])
@@ -274,6 +313,6 @@ def test_pack_unpack_roundtrip():
 def test_bad_arguments_are_rejected():
     x = torch.zeros(8, 12, device=DEV)
     with pytest.raises(hip.HipError):
-        call("fs2_conv_gemm", ptr(x), ptr(x), None, None, ptr(x), None, 8, 8, 12, 2, 12, 8, 8, 0, 1, 0, stream())
+        call("fs2_conv_gemm", ptr(x), ptr(x), None, None, ptr(x), None, 8, 8, 12, 2, 12, 8, 8, 0, 1, 0, 1, 0, stream())
     with pytest.raises(hip.HipError):
         call("fs2_attention", ptr(x), ptr(x), ptr(x), 1, 8, 1, 48, 144, 48, 0, stream())

@@ -165,8 +165,10 @@ def test_full_size_properties_bf16():
         idx, _ = fs2_oracle.length_regulate_index(d_b)
         assert np.array_equal(lri[cu_f[b]:cu_f[b + 1]], idx)
     assert torch.isfinite(out["mel"]).all()
-    for b in (0, 13, 31):                      # batch row == the same utterance alone
+    # batch row == the same utterance alone.  Not bit-equal: a 1-utterance launch picks other tile /
+    # split-K shapes, i.e. another fp32 summation order, and in bf16 that can flip activation roundings.
+    for b in (0, 13, 31):
         alone = model.infer_batch([xs[b]])
         if np.array_equal(alone["packed"]["durations"].cpu().numpy(), dur[cu_p[b]:cu_p[b + 1]]):
             T = pk["olens"][b]
-            assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= 1e-5
+            assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= BF16_MEL_TOL

@@ -73,7 +73,7 @@ def main():
 
         def fn():
             call("fs2_conv_gemm", ptr(x), ptr(w), ptr(b), ptr(res), ptr(out), ptr(seg) if taps > 1 else None, M, n, cin,
-                 taps, cin, n, n, int(relu), int(out_f32), code, stream())
+                 taps, cin, n, n, int(relu), int(out_f32), code, 1, 0, stream())
         med, mn = timeit(fn)
         fl = 2.0 * M * n * cin * taps
         print("%-30s M=%6d  %8.1f us (min %8.1f)  %7.1f TFLOP/s" % (name, M, med, mn, fl / med / 1e6), flush=True)
