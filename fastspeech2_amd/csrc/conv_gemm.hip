@@ -27,7 +27,6 @@
 
 namespace fs2 {
 
-constexpr int CG_THREADS = 256;
 constexpr int CG_MAX_TAPS = 9;
 constexpr int CG_HALO = CG_MAX_TAPS - 1;
 constexpr int CG_ROWB = 128;  // bytes per LDS row = one channel chunk
@@ -58,9 +57,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
     __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int MT, int NT, bool DMA, bool XDB>
-__global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(ConvGemmArgs a) {
-    constexpr int BM = 32 * MT, BN = 32 * NT;
+// MODE 0: generic register staging (any Cin % 8 == 0), X/W double-buffered, synchronous
+// MODE 1: LDS-DMA, X single + W double buffer, one __syncthreads per step (3 workgroups / CU)
+// MODE 2: LDS-DMA, X single + 3-stage W ring: the DMA of step s+2 is issued in the middle of step s
+//         and stays in flight across the end-of-step barrier (counted vmcnt + raw s_barrier)
+// Workgroup = 2 WM waves laid out WM (tokens) x 2 (channels); wave tile 16 MT x 16 NT; block tile
+// (16 MT WM) x (32 NT).  XDB: X image double-buffered (refill overlapped) or single (less LDS).
+// OCC: workgroups per CU the register allocation is tuned for.
+template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC>
+__global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_kernel(ConvGemmArgs a) {
+    constexpr bool DMA = MODE != 0;
+    constexpr int NW = 2 * WM;
+    constexpr int BM = 16 * MT * WM, BN = 32 * NT;
     constexpr int EPV = 16 / (int)sizeof(T);        // elements per 16-byte slot
     constexpr int BKE = CG_ROWB / (int)sizeof(T);   // channels per chunk (64 bf16 / 32 f32)
     constexpr int KSTEPS = BKE / 32;                // fragment steps per chunk
@@ -69,11 +77,11 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
     constexpr int W_BYTES = BN * CG_ROWB;
     constexpr int X_INSTR = XROWS / 8;              // 1-KiB (8-row) pieces of the X image
     constexpr int W_INSTR = BN / 8;
-    constexpr int XBUFS = XDB ? 2 : 1;            // X image single-buffered: 3 workgroups per CU fit in LDS
+    constexpr int XBUFS = XDB ? 2 : 1;
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [X buf0]([X buf1])[W buf0][W buf1]
+    // [X buf0]([X buf1])[W stage 0][W stage 1]([W stage 2])
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
     auto stage_x = [&](int chunk, int buf) __attribute__((always_inline)) {
         unsigned char* dst = smem + buf * X_BYTES;
         const int c0 = chunk * BKE;
-        for (int p = wave; p < X_INSTR; p += 4) {
+        for (int p = wave; p < X_INSTR; p += NW) {
             const int r = 8 * p + prow;
             int gm = m0 - pad + r;
             gm = gm < 0 ? 0 : (gm >= a.M ? a.M - 1 : gm);  // out-of-range rows are always masked
@@ -147,8 +155,9 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
         const int c0 = chunk * BKE;
         const T* wt = W + (size_t)tap * a.N * a.Cin;
 #pragma unroll
-        for (int q = 0; q < W_INSTR / 4; ++q) {
-            const int p = wave + 4 * q;
+        for (int q = 0; q < (W_INSTR + NW - 1) / NW; ++q) {
+            const int p = wave + NW * q;
+            if (W_INSTR % NW != 0 && p >= W_INSTR) break;
             const int r = 8 * p + prow;
             int n = n0 + r;
             n = n >= a.N ? a.N - 1 : n;                     // columns >= N are never stored
@@ -174,26 +183,11 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
     const int wrow_base = wn * (16 * NT) + (i >> 2) * (4 * NT) + (i & 3);
     const int xrow_base = wm * (16 * MT) + i;
 
-    if (nsteps > 0) {
-        stage_x(chunk_lo, 0);
-        stage_w(0, chunk_lo, 0);
-    }
-    __syncthreads();
-
-    int xcur = 0, wcur = 0;
-    int tap = 0, chunk = chunk_lo;
-    for (int step = 0; step < nsteps; ++step) {
-        int ntap = tap + 1, nchunk = chunk;
-        if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
-        const bool has_next = (step + 1) < nsteps;
-        const bool next_x = has_next && (ntap == 0);
-        if (DMA) {   // LDS-DMA prefetch of step+1 into the other buffers, in flight during the MFMAs
-            if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
-            if (XDB && next_x) stage_x(nchunk, xcur ^ 1);
-        }
-
-        const unsigned char* xs = smem + xcur * X_BYTES;
-        const unsigned char* ws = smem + XBUFS * X_BYTES + wcur * W_BYTES;
+    // one (tap, chunk) step of MFMAs out of X image `xbuf` and W stage `wbuf`; `mid()` runs between
+    // the two fragment steps (bf16) / after the fragment loads (f32): the place for DMA issue
+    auto compute = [&](int tap, int xbuf, int wbuf, auto&& mid) __attribute__((always_inline)) {
+        const unsigned char* xs = smem + xbuf * X_BYTES;
+        const unsigned char* ws = smem + XBUFS * X_BYTES + wbuf * W_BYTES;
         const int shift = tap - pad;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -227,25 +221,88 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
                 for (int mt = 0; mt < MT; ++mt)
                     if (shift < lo[mt] || shift > hi[mt]) xf[mt] = frag_zero<T>();
             }
+            if (ks == 0) mid();
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(wf[nt], xf[mt], acc[mt][nt]);
         }
+    };
 
-        if (!DMA) {  // generic path: synchronous register staging of step+1 (odd shapes only)
-            if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
-            if (XDB && next_x) stage_x(nchunk, xcur ^ 1);
+    if constexpr (MODE == 2) {
+        static_assert(W_INSTR % NW == 0, "ring mode needs an equal number of W pieces per wave");
+        constexpr int WP = W_INSTR / NW;           // W DMA pieces per wave per step
+        // step s -> (chunk_lo + s / taps, s % taps); W(s) lives in ring stage s % 3
+        if (nsteps > 0) {
+            stage_x(chunk_lo, 0);
+            stage_w(0, chunk_lo, 0);
+            if (nsteps > 1) {
+                const bool wrap = a.taps == 1;
+                stage_w(wrap ? 0 : 1, wrap ? chunk_lo + 1 : chunk_lo, 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");   // X + W(0) landed; W(1) in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
-        __syncthreads();   // also drains the LDS-DMA (vmcnt(0)) issued at the top of this step
-        if (!XDB && next_x) {   // single X image: refill it once per channel chunk, between two barriers
-            stage_x(nchunk, 0);
-            __syncthreads();
+        __builtin_amdgcn_s_barrier();
+        int tap = 0, chunk = chunk_lo;             // of step s
+        int tap2 = 2 % a.taps, chunk2 = chunk_lo + 2 / a.taps;   // of step s + 2
+        int ring = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            const bool issue = (s + 2) < nsteps;
+            const int ring2 = ring >= 1 ? ring - 1 : 2;            // (s + 2) % 3
+            compute(tap, 0, ring, [&]() __attribute__((always_inline)) {
+                // ring stage (s+2)%3 == (s-1)%3 was last read in step s-1; every wave has passed the
+                // barrier that ended it
+                if (issue) stage_w(tap2, chunk2, ring2);
+            });
+            const bool last_tap = (tap + 1) == a.taps;
+            // W(s+1) (issued during step s-1) must have landed; the WP pieces of W(s+2) may stay in flight
+            if (issue)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WP) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (last_tap && (s + 1) < nsteps) {   // every wave is done with X(chunk): refill the single image
+                stage_x(chunk + 1, 0);
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            ring = ring == 2 ? 0 : ring + 1;
+            if (++tap == a.taps) { tap = 0; ++chunk; }
+            if (++tap2 == a.taps) { tap2 = 0; ++chunk2; }
         }
-        wcur ^= 1;
-        if (XDB && next_x) xcur ^= 1;
-        tap = ntap;
-        chunk = nchunk;
+    } else {
+        if (nsteps > 0) {
+            stage_x(chunk_lo, 0);
+            stage_w(0, chunk_lo, 0);
+        }
+        __syncthreads();
+
+        int xcur = 0, wcur = 0;
+        int tap = 0, chunk = chunk_lo;
+        for (int step = 0; step < nsteps; ++step) {
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
+            const bool has_next = (step + 1) < nsteps;
+            const bool next_x = has_next && (ntap == 0);
+            if (DMA) {   // LDS-DMA prefetch of step+1 into the other W buffer, in flight during the MFMAs
+                if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
+                if (XDB && next_x) stage_x(nchunk, xcur ^ 1);
+            }
+            compute(tap, xcur, wcur, []() {});
+            if (!DMA) {  // generic path: synchronous register staging of step+1 (odd shapes only)
+                if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
+                if (next_x) stage_x(nchunk, xcur ^ 1);
+            }
+            __syncthreads();   // also drains the LDS-DMA (vmcnt(0)) issued at the top of this step
+            if (DMA && !XDB && next_x) {   // single X image: refill it once per channel chunk, between two barriers
+                stage_x(nchunk, 0);
+                __syncthreads();
+            }
+            wcur ^= 1;
+            if (XDB && next_x) xcur ^= 1;
+            tap = ntap;
+            chunk = nchunk;
+        }
     }
 
     // ---- epilogue: lane (g, i) holds token m = .. + 16 mt + i, channels nb .. nb + 4 NT - 1 with
@@ -295,16 +352,28 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
                     if (mok && nok[nt]) *(f32x4*)(o + ncl[nt]) = v[nt];
             } else {
                 T* o = (T*)a.out + (size_t)blockIdx.y * a.split_stride + mc * a.ldo;
+                if constexpr (sizeof(T) == 2 && (NT % 2) == 0) {
+                    // channels nb + 8 j .. nb + 8 j + 7 as one 16-byte store when the row allows it
+                    const bool wide = ((a.ldo & 7) == 0) && ((nb & 7) == 0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    T t4[4];
+                    for (int j = 0; j < NT / 2; ++j) {
+                        T t8[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t4[r] = from_f32<T>(v[nt][r]);
-                    if (mok && nok[nt]) {
-                        if constexpr (sizeof(T) == 2)
-                            *(uint2*)(o + ncl[nt]) = *(const uint2*)t4;
-                        else
-                            *(f32x4*)(o + ncl[nt]) = *(const f32x4*)t4;
+                        for (int r = 0; r < 4; ++r) {
+                            t8[r] = from_f32<T>(v[2 * j][r]);
+                            t8[4 + r] = from_f32<T>(v[2 * j + 1][r]);
+                        }
+                        if (wide && mok && nok[2 * j + 1]) {
+                            *(vec16*)(o + ncl[2 * j]) = *(const vec16*)t8;
+                        } else {
+                            if (mok && nok[2 * j]) *(uint2*)(o + ncl[2 * j]) = *(const uint2*)t8;
+                            if (mok && nok[2 * j + 1]) *(uint2*)(o + ncl[2 * j + 1]) = *(const uint2*)(t8 + 4);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (mok && nok[nt]) store4<T>(o + ncl[nt], v[nt]);
                     }
                 }
             }
@@ -334,19 +403,20 @@ __global__ __launch_bounds__(CG_THREADS, XDB ? 2 : 3) void conv_gemm_kernel(Conv
     }
 }
 
-template <typename T, int MT, int NT, bool DMA, bool XDB>
+template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
-    constexpr int BM = 32 * MT, BN = 32 * NT;
-    constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
+    constexpr int BM = 16 * MT * WM, BN = 32 * NT;
+    constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + (MODE == 2 ? 3 : 2) * BN * CG_ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, DMA, XDB>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     a.n_tiles = (a.N + BN - 1) / BN;
     const int m_tiles = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, DMA, XDB>), dim3(a.n_tiles * m_tiles, a.ksplit), dim3(CG_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC>), dim3(a.n_tiles * m_tiles, a.ksplit),
+                       dim3(128 * WM), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_conv_gemm");
     return FS2_OK;
 }
@@ -357,11 +427,12 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const bool dma = (a.Cin % BKE) == 0;
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
     const bool small = big_blocks < 200;   // would leave most of the 256 CUs idle: use 64x64 tiles
-    if (dma) {
-        if (small) return launch_conv_gemm<T, 2, 2, true, true>(a, stream);
-        return launch_conv_gemm<T, 4, 4, true, false>(a, stream);
-    }
-    return small ? launch_conv_gemm<T, 2, 2, false, true>(a, stream) : launch_conv_gemm<T, 4, 4, false, true>(a, stream);
+    if (!dma) return small ? launch_conv_gemm<T, 2, 2, 2, 0, true, 2>(a, stream) : launch_conv_gemm<T, 4, 4, 2, 0, true, 2>(a, stream);
+    if (small) return launch_conv_gemm<T, 2, 2, 2, 1, false, 4>(a, stream);
+    // 128x128, X image single-buffered: 50 KB of LDS -> 3 workgroups per CU.  Measured on MI355X (config-2
+    // decoder FFN, bf16, random data): 128.1 us vs 154 us for the double-buffered-X / 2 WG per CU form,
+    // 155 us for the 3-stage ring (MODE 2), 145-180 us for 8-wave 128x128 / 256x128 and 128x64 tiles.
+    return launch_conv_gemm<T, 4, 4, 2, 1, false, 3>(a, stream);
 }
 
 }  // namespace fs2
