@@ -172,3 +172,26 @@ def test_full_size_properties_bf16():
         if np.array_equal(alone["packed"]["durations"].cpu().numpy(), dur[cu_p[b]:cu_p[b + 1]]):
             T = pk["olens"][b]
             assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= BF16_MEL_TOL
+
+
+def test_decode_entry_point():
+    """run/fastspeech_decode.py:decode counterpart: eval+no_grad, controls, 8 fields, restores train()."""
+    from argparse import Namespace
+    from fastspeech2_amd.run.fastspeech_decode import decode
+    z, meta = helpers.load_golden("tiny_linear_scaled")
+    model = build_model(meta)
+    model.train()
+    utts = {"utt%d" % i: z["ids_%d" % i] for i in range(meta["n"])}
+    cfg = Namespace(DATASET=Namespace(VAL=Namespace(UTTERANCES=utts)), DECODE=Namespace(BATCH_SIZE=2))
+    res = decode(cfg, model, 0, None)
+    assert model.training
+    for i in range(meta["n"]):
+        r = res["utt%d" % i]
+        assert set(r) == {"mel", "mel_postnet", "durations", "pitch", "energy", "src_mask", "mel_mask", "mel_length"}
+        assert r["mel_length"] == int(z["frames_%d" % i])
+        assert np.array_equal(r["durations"], z["dur_after_lr_%d" % i])
+        assert np.abs(r["mel"] - z["mel_%d" % i]).max() <= FP32_MEL_TOL
+    # two "ranks" partition the set
+    r0 = decode(cfg, model, 0, None, rank=0, world_size=2)
+    r1 = decode(cfg, model, 0, None, rank=1, world_size=2)
+    assert sorted(list(r0) + list(r1)) == sorted(utts)
