@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--encoder-dtype", default=None, choices=[None, "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=2)
+    ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
     return ap.parse_args()
 
 
