@@ -141,9 +141,13 @@ def main():
         n = len(recs)
         achieved = fl / (t_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
+        traffic = None     # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        tpath = os.path.join(ROOT, "profiles", "r01_ffn_conv_traffic.json")
+        if args.dtype == "bf16" and os.path.isfile(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roofline = dict(bound="mfma", kernel="fs2::conv_gemm_kernel<%s> (FFN conv k=9, both convs)" % args.dtype,
                         achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                        traffic=None, launches=n, avg_launch_us=round(t_ms * 1e3 / n, 2),
+                        traffic=traffic, launches=n, avg_launch_us=round(t_ms * 1e3 / n, 2),
                         flops_per_launch=fl / n)
 
     cpu = None
