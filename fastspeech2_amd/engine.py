@@ -278,6 +278,13 @@ class Engine:
         overrides (teacher forcing): durations int32 [Mp], pitch fp32 [Mf,4], energy fp32 [Mf,1].
         Returns packed outputs; `olens` is a host list (one device->host read of B+1 integers is the
         only synchronisation of the forward)."""
+        ctx = self.phone_phase(ids, ilens, duration_control, ds, want_attention)
+        return self.frame_phase(ctx, ps, es, pitch_control, energy_control)
+
+    def phone_phase(self, ids, ilens, duration_control=1.0, ds=None, want_attention=False) -> Dict[str, object]:
+        """Phone-level half: embedding, encoder stack, duration predictor, LengthRegulator planning.
+        Everything is enqueued on the current stream; the B+1 frame offsets are copied to pinned host
+        memory asynchronously and an event marks the end (no host wait here)."""
         dev, d = self.dev, self.d
         B = len(ilens)
         ilens = [int(v) for v in ilens]
@@ -303,7 +310,7 @@ class Engine:
         enc_att = [] if want_attention else None
         hs32, hst = self._run_stack(self.enc, x32, xt, seg_p, cu_phone, B, max_il, Mp, enc_att, ilens)
 
-        # ---- variance adaptor (network/variance_adaptor.py:195-207 with D6)
+        # ---- variance adaptor, phone side (network/variance_adaptor.py:195-201 with D6)
         logd = self._predict(self.dur_pred, hst, seg_p, Mp, d).view(-1)
         dur_pred = self._empty((max(Mp, 1),), dtype=torch.int32)
         call("fs2_duration_round", ptr(logd), ptr(dur_pred), Mp, stream())
@@ -314,10 +321,31 @@ class Engine:
         cu_frames = self._empty((B + 1,), dtype=torch.int32)
         call("fs2_lr_plan", ptr(dur_in), ptr(cu_phone), float(duration_control), ptr(dur_used), ptr(cum),
              ptr(olens_dev), ptr(cu_frames), B, stream())
-        cu_f = cu_frames.cpu().numpy()                      # the one host sync
+        cu_host = torch.empty((B + 1,), dtype=torch.int32, pin_memory=True)
+        cu_host.copy_(cu_frames, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return dict(B=B, Mp=Mp, ilens=ilens, cu_phone=cu_phone, hs32=hs32, cum=cum, cu_frames=cu_frames,
+                    cu_host=cu_host, done=done, dur_used=dur_used, dur_pred=dur_pred, logd=logd, enc_att=enc_att,
+                    stream=torch.cuda.current_stream(), keep=(ids, dur_in, olens_dev))
+
+    def frame_phase(self, ctx, ps=None, es=None, pitch_control=1.0, energy_control=1.0) -> Dict[str, object]:
+        """Frame-level half: LengthRegulator gather, pitch/energy predictors + embeddings, decoder stack,
+        feat_out.  Waits (host) for the phone phase's frame offsets — the one synchronisation."""
+        dev, d = self.dev, self.d
+        B, Mp = ctx["B"], ctx["Mp"]
+        cur = torch.cuda.current_stream()
+        if ctx["stream"] != cur:                # phone phase ran on another stream: order + keep memory alive
+            cur.wait_event(ctx["done"])
+            for t in (ctx["cu_phone"], ctx["hs32"], ctx["cum"], ctx["cu_frames"], ctx["dur_used"], ctx["dur_pred"],
+                      ctx["logd"]):
+                t.record_stream(cur)
+        ctx["done"].synchronize()
+        cu_f = ctx["cu_host"].numpy()
         olens = np.diff(cu_f).astype(np.int64).tolist()
         Mf = int(cu_f[-1])
         max_ol = max(olens) if B else 0
+        cu_phone, cu_frames, hs32, cum = ctx["cu_phone"], ctx["cu_frames"], ctx["hs32"], ctx["cum"]
 
         dc = self.dec_code
         hs_lr32 = self._empty((Mf, d), dtype=torch.float32)
@@ -345,15 +373,38 @@ class Engine:
              ptr(yt), Mf, d, self.pdim, self.edim, dc, stream())
         if dc == F32:
             yt = y32
-        dec_att = [] if want_attention else None
+        dec_att = [] if ctx["enc_att"] is not None else None
         z32, zt = self._run_stack(self.dec, y32, yt, seg_f, cu_frames, B, max_ol, Mf, dec_att, olens)
         mel = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True)
-        out = dict(mel=mel, olens=olens, cu_frames=cu_frames, cu_phone=cu_phone, durations=dur_used[:Mp],
-                   durations_pred=dur_pred[:Mp], log_durations=logd, pitch=pitch, energy=energy,
+        out = dict(mel=mel, olens=olens, cu_frames=cu_frames, cu_phone=cu_phone, durations=ctx["dur_used"][:Mp],
+                   durations_pred=ctx["dur_pred"][:Mp], log_durations=ctx["logd"], pitch=pitch, energy=energy,
                    lr_index=lr_index[:Mf], enc_out=hs32, frames=Mf)
-        if want_attention:
-            out["enc_attention"], out["dec_attention"] = enc_att, dec_att
+        if dec_att is not None:
+            out["enc_attention"], out["dec_attention"] = ctx["enc_att"], dec_att
         return out
+
+    def forward_pipelined(self, batches, **kw):
+        """Throughput mode for a stream of batches [(ids, ilens), ...]: the phone phase of batch k+1 (small
+        grids that cannot fill 256 CUs) runs on a side stream underneath the frame phase of batch k.
+        Same kernels, same results as `forward`; yields one output dict per batch, in order."""
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        it = iter(batches)
+
+        def launch_phone(b):
+            self._side.wait_stream(main)       # inputs prepared on the main stream
+            with torch.cuda.stream(self._side):
+                return self.phone_phase(b[0], b[1], kw.get("duration_control", 1.0))
+        try:
+            ctx = launch_phone(next(it))
+        except StopIteration:
+            return
+        while ctx is not None:
+            nxt = next(it, None)
+            nctx = launch_phone(nxt) if nxt is not None else None
+            yield self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))
+            ctx = nctx
 
     def unpack(self, packed: torch.Tensor, cu: torch.Tensor, B: int, Tmax: int) -> torch.Tensor:
         """packed [M, C] fp32 -> zero-padded [B, Tmax, C] (pad_list, network/utils.py:50-56)."""

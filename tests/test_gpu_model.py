@@ -195,3 +195,22 @@ def test_decode_entry_point():
     r0 = decode(cfg, model, 0, None, rank=0, world_size=2)
     r1 = decode(cfg, model, 0, None, rank=1, world_size=2)
     assert sorted(list(r0) + list(r1)) == sorted(utts)
+
+
+def test_pipelined_forward_equals_serial():
+    """Engine.forward_pipelined (phone phase of batch k+1 on a side stream) gives the serial results."""
+    z, meta = helpers.load_golden("tiny_conv3_mixed_ln")
+    model = build_model(meta)
+    eng = model.engine()
+    rng = np.random.Generator(np.random.PCG64(4))
+    batches = []
+    for k in range(5):
+        xs = [rng.integers(1, meta["cfg"]["idim"], size=int(L)) for L in rng.integers(3, 40, size=3)]
+        batches.append((torch.from_numpy(np.concatenate(xs)).cuda(), [len(x) for x in xs]))
+    serial = [eng.forward(ids, il) for ids, il in batches]
+    piped = list(eng.forward_pipelined(batches))
+    assert len(piped) == len(serial)
+    for a, b in zip(serial, piped):
+        assert a["olens"] == b["olens"]
+        assert torch.equal(a["durations"], b["durations"])
+        assert torch.equal(a["mel"], b["mel"])

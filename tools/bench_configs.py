@@ -1,0 +1,33 @@
+"""Latency / throughput of the other BASELINE.json configs (not the bench line): config 1 (B=1, 120
+phones), config 4 (long utterance: 512 phones -> ~4000 frames, B=1 and B=4), fp32 and bf16."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from fastspeech2_amd import synth
+
+def run(eng, xs, iters=20):
+    ilens = [len(x) for x in xs]
+    ids = torch.from_numpy(np.concatenate(xs)).cuda()
+    for _ in range(3):
+        out = eng.forward(ids, ilens)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = eng.forward(ids, ilens)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    fr = sum(out["olens"])
+    return dt * 1e3, fr, fr / dt
+
+for dtype in ("bf16", "fp32"):
+    model, _, _ = bench.build_model(dtype, None, torch.device("cuda", 0))
+    eng = model.engine()
+    rng = np.random.Generator(np.random.PCG64(0))
+    cases = {"config1 B=1 120 phones": [rng.integers(1, 80, size=120)],
+             "config4 B=1 512 phones": [rng.integers(1, 80, size=512)],
+             "config4 B=4 512 phones": [rng.integers(1, 80, size=512) for _ in range(4)],
+             "config2 B=32": synth.synth_utterances(32, 0)}
+    for name, xs in cases.items():
+        ms, fr, fps = run(eng, xs)
+        print("%-5s %-24s %8.3f ms  frames=%6d  %10.0f frames/s  RTF=%.2e" % (dtype, name, ms, fr, fps, ms * 1e-3 / (fr * bench.HOP_SECONDS)), flush=True)
