@@ -40,7 +40,7 @@ struct ConvGemmArgs {
     const int2* seg;     // [M] (start,end) row range of the row's utterance; null when taps == 1
     int M, N, Cin, taps;
     int ldx, ldr, ldo;
-    int relu, out_f32;
+    int relu, out_f32;        // relu: activation code 0 none / 1 ReLU / 2 tanh
     int n_tiles;
     int ksplit;               // split of the channel-chunk range over gridDim.y partial outputs
     long long split_stride;   // elements between two partial outputs
@@ -332,11 +332,16 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             f32x4 v[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + bv[nt];
-            if (a.relu) {
+            if (a.relu == 1) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[nt][r] = fmaxf(v[nt][r], 0.f);
+            } else if (a.relu == 2) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] = tanhf(v[nt][r]);
             }
             if (a.res) {
                 f32x4 rv[NT];
@@ -391,7 +396,8 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                     if (n >= a.N) continue;
                     float s = acc[mt][nt][r];
                     if (bias) s += bias[n];
-                    if (a.relu) s = fmaxf(s, 0.f);
+                    if (a.relu == 1) s = fmaxf(s, 0.f);
+                    if (a.relu == 2) s = tanhf(s);
                     if (a.res) s += a.res[(size_t)m * a.ldr + n];
                     const size_t oidx = (size_t)blockIdx.y * a.split_stride + (size_t)m * a.ldo + n;
                     if (a.out_f32)
@@ -440,7 +446,8 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 // dtype: 0 = f32, 1 = bf16 (include/fs2_hip.h)
 extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out,
                              const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
-                             int relu, int out_f32, int dtype, int ksplit, long long split_stride,
+                             int relu /* activation: 0 none, 1 ReLU, 2 tanh */, int out_f32, int dtype, int ksplit,
+                             long long split_stride,
                              hipStream_t stream) {
     using namespace fs2;
     FS2_CHECK_ARG(X && W && out, "fs2_conv_gemm: null X/W/out");
@@ -449,6 +456,7 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
                   CG_MAX_TAPS);
     FS2_CHECK_ARG(taps == 1 || seg, "fs2_conv_gemm: taps>1 needs the per-row segment table");
     FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_conv_gemm: dtype=%d", dtype);
+    FS2_CHECK_ARG(relu >= 0 && relu <= 2, "fs2_conv_gemm: activation code %d (0 none, 1 relu, 2 tanh)", relu);
     const int epv = dtype == 0 ? 4 : 8;
     FS2_CHECK_ARG(Cin % epv == 0 && ldx % epv == 0 && ldx >= Cin,
                   "fs2_conv_gemm: Cin=%d / ldx=%d must be multiples of %d (16-byte rows)", Cin, ldx, epv);

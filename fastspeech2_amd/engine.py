@@ -112,9 +112,6 @@ class Engine:
             raise NotImplementedError("head dim %d: the attention kernel supports 32/64/96/128" % self.dk)
         if cfg["positionwise_layer_type"] not in ("linear", "conv1d"):
             raise NotImplementedError("not implemented")          # network/encoder.py:232
-        if cfg["postnet_layers"] != 0:
-            raise NotImplementedError("PostNet is defective in the reference (SURVEY.md D7); "
-                                      "use postnet_layers=0")
         if cfg["reduction_factor"] != 1:
             raise NotImplementedError("reduction_factor != 1")
         sd, dev = state_dict, self.dev
@@ -147,6 +144,19 @@ class Engine:
         self.w_out = g("feat_out.weight").to(hip.TORCH_DTYPE[self.dec_code]).contiguous()
         self.b_out = g("feat_out.bias")
         self.odim = self.w_out.shape[0]
+        # repaired PostNet: eval-mode BatchNorm folded into the conv (scale on W, shift as bias)
+        self.postnet = []
+        tdt = hip.TORCH_DTYPE[self.dec_code]
+        for j in range(cfg["postnet_layers"]):
+            w = g("postnet.postnet.%d.0.weight" % j)                        # (Cout, Cin, k), bias=False
+            bias = torch.zeros(w.shape[0], device=dev)
+            if cfg.get("use_batch_norm", True):
+                p = "postnet.postnet.%d.1." % j
+                scale = g(p + "weight") / torch.sqrt(g(p + "running_var") + 1e-5)
+                bias = g(p + "bias") - g(p + "running_mean") * scale
+                w = w * scale.view(-1, 1, 1)
+            self.postnet.append(dict(w=w.permute(2, 0, 1).to(tdt).contiguous(), b=bias.contiguous(), taps=w.shape[-1],
+                                     cout=w.shape[0], cin=w.shape[1]))
         self._pe = None
         self.profile = None     # optional list collecting (tag, start_event, end_event)
 
@@ -375,8 +385,20 @@ class Engine:
             yt = y32
         dec_att = [] if ctx["enc_att"] is not None else None
         z32, zt = self._run_stack(self.dec, y32, yt, seg_f, cu_frames, B, max_ol, Mf, dec_att, olens)
-        mel = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True)
-        out = dict(mel=mel, olens=olens, cu_frames=cu_frames, cu_phone=cu_phone, durations=ctx["dur_used"][:Mp],
+        before = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True)
+        mel = before
+        if self.postnet:      # after = before + postnet(before)   (network/fastspeech2.py:222-225)
+            cur = before
+            if dc != F32:
+                cur = self._empty((Mf, self.odim), dc)
+                call("fs2_cast", ptr(before), ptr(cur), Mf * self.odim, dc, stream())
+            for j, L in enumerate(self.postnet):
+                last = j == len(self.postnet) - 1
+                cur = self._gemm(cur, L["w"], L["b"], Mf, L["cout"], L["cin"], L["taps"], dc,
+                                 seg=seg_f if L["taps"] > 1 else None, res=before if last else None,
+                                 relu=0 if last else 2, out_f32=last)
+            mel = cur
+        out = dict(mel=mel, mel_before=before, olens=olens, cu_frames=cu_frames, cu_phone=cu_phone, durations=ctx["dur_used"][:Mp],
                    durations_pred=ctx["dur_pred"][:Mp], log_durations=ctx["logd"], pitch=pitch, energy=energy,
                    lr_index=lr_index[:Mf], enc_out=hs32, frames=Mf)
         if dec_att is not None:

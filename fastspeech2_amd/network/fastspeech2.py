@@ -94,6 +94,23 @@ def _embedder(in_dim, out_dim, k):
     return e
 
 
+def _postnet(odim, n_layers, chans, filts, use_batch_norm, dropout):
+    pn = _Holder()
+    layers = []
+    for j in range(n_layers):
+        cin = odim if j == 0 else chans
+        cout = odim if j == n_layers - 1 else chans
+        mods = [nn.Conv1d(cin, cout, filts, padding=(filts - 1) // 2, bias=False)]
+        if use_batch_norm:
+            mods.append(nn.BatchNorm1d(cout))
+        if j != n_layers - 1:
+            mods.append(nn.Tanh())
+        mods.append(nn.Dropout(dropout))
+        layers.append(nn.Sequential(*mods))
+    pn.postnet = nn.ModuleList(layers)
+    return pn
+
+
 class FeedForwardTransformer(nn.Module):
     def __init__(self,
                  idim: int,
@@ -148,7 +165,8 @@ class FeedForwardTransformer(nn.Module):
             duration_predictor_layers=duration_predictor_layers, duration_predictor_chans=duration_predictor_chans,
             duration_predictor_kernel_size=duration_predictor_kernel_size, dlayers=dlayers, dunits=dunits,
             decoder_normalized_before=decoder_normalized_before, decoder_concat_after=decoder_concat_after,
-            reduction_factor=reduction_factor, postnet_layers=postnet_layers, use_masking=use_masking,
+            reduction_factor=reduction_factor, postnet_layers=postnet_layers, use_batch_norm=use_batch_norm,
+            use_masking=use_masking,
             use_scaled_pos_enc=use_scaled_pos_enc)
 
         # same construction order as network/fastspeech2.py:116-167 -> same RNG consumption
@@ -168,10 +186,11 @@ class FeedForwardTransformer(nn.Module):
         self.decoder = _fft_stack(adim, aheads, dunits, dlayers, decoder_normalized_before, decoder_concat_after,
                                   positionwise_layer_type, positionwise_conv_kernel_size, use_scaled_pos_enc, None)
         self.feat_out = nn.Linear(adim, odim * reduction_factor)
-        # The reference PostNet cannot run (4 of 5 layers, wrong in/out channels).
-        # It is outside this round's scope (§8f rank 1): constructing with postnet_layers > 0 works
-        # (so param/fastspeech.yaml loads), running the forward with it raises.
-        self.postnet = None
+        # The reference PostNet cannot run as written (n-1 layers, idim input channels, never
+        # emits odim).  This is the repaired ESPnet layout: n x [Conv1d(k, bias=False), BatchNorm1d, tanh
+        # (not on the last layer), dropout], odim -> chans -> ... -> odim; `after = before + postnet(before)`.
+        self.postnet = None if postnet_layers == 0 else _postnet(odim, postnet_layers, postnet_chans, postnet_filts,
+                                                                 use_batch_norm, postnet_dropout_rate)
         self.postnet_layers = postnet_layers
 
         initialize(self, transformer_init)
@@ -196,14 +215,10 @@ class FeedForwardTransformer(nn.Module):
 
     def engine(self):
         from ..engine import Engine
-        params = list(self.parameters())
+        params = list(self.parameters()) + list(self.buffers())
         dev = params[0].device
         key = (self._precision, str(dev), tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
         if self._engine is None or key != self._engine_key:
-            if self.postnet_layers != 0:
-                raise NotImplementedError("postnet_layers=%d: the reference PostNet is defective (SURVEY.md D7) "
-                                          "and not part of this build; construct with postnet_layers=0"
-                                          % self.postnet_layers)
             if dev.type != "cuda":
                 from ..hip import HipError
                 raise HipError("model parameters are on %s: move the model to the MI355X (`model.cuda()`); the "
@@ -251,8 +266,8 @@ class FeedForwardTransformer(nn.Module):
                 es_p = self._pack(es.to(eng.dev), ol).float().contiguous()
                 out = eng.forward(ids, il, ds=ds_p, ps=ps_p, es=es_p)
             Tmax = max(out["olens"]) if B else 0
-            before = eng.unpack(out["mel"], out["cu_frames"], B, Tmax)
-        after = before                                   # postnet is None (:222-223)
+            after = eng.unpack(out["mel"], out["cu_frames"], B, Tmax)
+            before = after if self.postnet is None else eng.unpack(out["mel_before"], out["cu_frames"], B, Tmax)
         if _raw:
             return before, after, out
         if is_inference:
@@ -287,6 +302,8 @@ class FeedForwardTransformer(nn.Module):
         es_p = self._pack(es.to(dev), ol).float()
         ds_p = self._pack(ds.to(dev), il)
         l1_loss = F.l1_loss(out["mel"], ys_p)
+        if self.postnet is not None:                                   # network/fastspeech2.py:271-274
+            l1_loss = l1_loss + F.l1_loss(out["mel_before"], ys_p)
         duration_loss = self.duration_criterion(out["log_durations"], ds_p)
         pitch_loss = self.mse_criterion(out["pitch"], ps_p)
         energy_loss = self.mse_criterion(out["energy"], es_p)

@@ -19,7 +19,8 @@ _DEFAULTS = dict(
     pitch_embed_kernel_size=1, energy_embed_kernel_size=1,
     duration_predictor_layers=2, duration_predictor_chans=256, duration_predictor_kernel_size=3,
     dlayers=6, dunits=1536, decoder_normalized_before=False, decoder_concat_after=False,
-    reduction_factor=1, postnet_layers=5, use_scaled_pos_enc=True,
+    reduction_factor=1, postnet_layers=5, postnet_filts=5, postnet_chans=256, use_batch_norm=True,
+    use_scaled_pos_enc=True,
 )
 
 # VariancePredictor defaults that the model constructor does not forward
@@ -105,8 +106,18 @@ def state_dict_spec(idim: int, odim: int, **kw) -> List[Tuple[str, Tuple[int, ..
           c["decoder_concat_after"], False)
     spec.append(("feat_out.weight", (odim * c["reduction_factor"], d), "w"))
     spec.append(("feat_out.bias", (odim * c["reduction_factor"],), "b"))
-    if c["postnet_layers"] != 0:
-        raise NotImplementedError("synthetic weights cover postnet_layers=0 (SURVEY.md D7)")
+    # repaired PostNet: n layers, first conv takes odim channels, the last one emits odim
+    n = c["postnet_layers"]
+    for j in range(n):
+        cin = odim if j == 0 else c["postnet_chans"]
+        cout = odim if j == n - 1 else c["postnet_chans"]
+        spec.append(("postnet.postnet.%d.0.weight" % j, (cout, cin, c["postnet_filts"]), "w"))
+        if c["use_batch_norm"]:
+            spec.append(("postnet.postnet.%d.1.weight" % j, (cout,), "ln_w"))
+            spec.append(("postnet.postnet.%d.1.bias" % j, (cout,), "ln_b"))
+            spec.append(("postnet.postnet.%d.1.running_mean" % j, (cout,), "ln_b"))
+            spec.append(("postnet.postnet.%d.1.running_var" % j, (cout,), "var"))
+            spec.append(("postnet.postnet.%d.1.num_batches_tracked" % j, (), "nbt"))
     return spec
 
 
@@ -129,6 +140,11 @@ def synth_state_dict(idim: int, odim: int, seed: int, dur_bias: float = None, al
             w = np.float32(1.0) + np.float32(0.1) * rng.standard_normal(shape, dtype=np.float32)
         elif kind == "ln_b":
             w = np.float32(0.1) * rng.standard_normal(shape, dtype=np.float32)
+        elif kind == "var":
+            w = np.float32(0.5) + np.abs(rng.standard_normal(shape, dtype=np.float32))
+        elif kind == "nbt":
+            out[key] = np.array(0, dtype=np.int64)
+            continue
         elif kind == "alpha":
             w = np.array(alpha, dtype=np.float32)
         else:

@@ -63,7 +63,8 @@ int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long 
                       int dtype, hipStream_t stream);
 
 /* Conv1d over time ("same" zero padding inside each utterance) or Linear (taps == 1) as an MFMA
- * implicit GEMM:  out = [relu](sum_tap X[m+tap-pad,:] . W[tap]^T + bias) [+ res]
+ * implicit GEMM:  out = act(sum_tap X[m+tap-pad,:] . W[tap]^T + bias) [+ res],  act = `relu` code:
+ * 0 none, 1 ReLU, 2 tanh (PostNet)
  * X [M,ldx] T; W packed [taps][N][Cin] T; bias fp32 [N] or NULL; res fp32 [M,ldr] or NULL;
  * out [M,ldo] fp32 (out_f32=1) or T.  seg is required when taps > 1.
  * Replaces nn.Conv1d in MultiLayeredConv1d (network/encoder.py:16-30) and ConvNorm

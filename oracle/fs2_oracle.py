@@ -32,7 +32,7 @@ DEFAULT_CFG = dict(
     eunits=1536, elayers=6, encoder_normalized_before=True, encoder_concat_after=False,
     duration_predictor_layers=2, duration_predictor_chans=256, duration_predictor_kernel_size=3,
     dlayers=6, dunits=1536, decoder_normalized_before=False, decoder_concat_after=False,
-    reduction_factor=1, postnet_layers=5, use_masking=True, use_scaled_pos_enc=True,
+    reduction_factor=1, postnet_layers=5, use_batch_norm=True, use_masking=True, use_scaled_pos_enc=True,
 )
 
 
@@ -227,10 +227,34 @@ def encode(sd, cfg, x_ids: torch.Tensor, attens=None) -> torch.Tensor:
     return fft_stack(emb, sd, "encoder.", has_embedding=True, attens=attens, **_enc_kw(cfg))
 
 
-def decode(sd, cfg, hs: torch.Tensor, attens=None) -> torch.Tensor:
-    """decoder stack + feat_out (network/fastspeech2.py:218-219); postnet_layers must be 0 (D7)."""
+BN_EPS = 1e-5   # nn.BatchNorm1d default (network/fastspeech2.py:35)
+
+
+def postnet(sd, cfg, before: torch.Tensor) -> torch.Tensor:
+    """REPAIRED PostNet (network/fastspeech2.py:13-54 builds only n-1 layers, feeds idim
+    channels and never emits odim, so the literal code cannot run): n layers of Conv1d(k, bias=False) ->
+    [BatchNorm1d, eval] -> tanh (not on the last layer) -> dropout(eval), first conv from odim channels,
+    last conv to odim.  Returns the residual branch postnet(before) as (T, odim)."""
+    y = before.t().unsqueeze(0)
+    n = cfg["postnet_layers"]
+    for j in range(n):
+        w = sd["postnet.postnet.%d.0.weight" % j]
+        y = F.conv1d(y, w, None, padding=(w.shape[-1] - 1) // 2)
+        if cfg["use_batch_norm"]:
+            p = "postnet.postnet.%d.1." % j
+            y = F.batch_norm(y, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"],
+                             False, 0.0, BN_EPS)
+        if j != n - 1:
+            y = torch.tanh(y)
+    return y.squeeze(0).t()
+
+
+def decode(sd, cfg, hs: torch.Tensor, attens=None, return_before: bool = False):
+    """decoder stack + feat_out (+ repaired postnet): network/fastspeech2.py:218-225."""
     zs = fft_stack(hs, sd, "decoder.", has_embedding=False, attens=attens, **_dec_kw(cfg))
-    return F.linear(zs, sd["feat_out.weight"], sd["feat_out.bias"]).view(-1, cfg["odim"])
+    before = F.linear(zs, sd["feat_out.weight"], sd["feat_out.bias"]).view(-1, cfg["odim"])
+    after = before if cfg["postnet_layers"] == 0 else before + postnet(sd, cfg, before)
+    return (before, after) if return_before else after
 
 
 def infer_one(sd, cfg, x_ids: torch.Tensor, duration_control: float = 1.0,
@@ -241,7 +265,6 @@ def infer_one(sd, cfg, x_ids: torch.Tensor, duration_control: float = 1.0,
     VarianceAdaptor.inference with D6 (variance_adaptor.py:195-207), one unpadded utterance.
     `ds` / `ps` / `es`, when given, replace the predicted durations / pitch / energy that feed the
     LengthRegulator and the embeddings (teacher forcing, VarianceAdaptor.forward :178-193)."""
-    assert cfg["postnet_layers"] == 0, "oracle covers postnet_layers=0 (SURVEY D7)"
     with torch.no_grad():
         hs = encode(sd, cfg, x_ids)
         logd = duration_log(hs, sd)
@@ -256,9 +279,9 @@ def infer_one(sd, cfg, x_ids: torch.Tensor, duration_control: float = 1.0,
         p_in = p_outs * pitch_control if ps is None else ps
         e_in = e_outs * energy_control if es is None else es
         hs_va = hs_lr + (variance_embed(e_in, sd, "energy") + variance_embed(p_in, sd, "pitch"))
-        mel = decode(sd, cfg, hs_va)
+        before, mel = decode(sd, cfg, hs_va, return_before=True)
     d_report = torch.from_numpy(d_fixed) if ds is None and duration_control == 1.0 else d_pred
-    return dict(mel=mel, durations=torch.from_numpy(d_fixed), durations_pred=d_pred,
+    return dict(mel=mel, mel_before=before, durations=torch.from_numpy(d_fixed), durations_pred=d_pred,
                 durations_reported=d_report, log_durations=logd, lr_index=idx_t,
                 enc_out=hs, hs_lr=hs_lr, hs_va=hs_va, pitch=p_outs, energy=e_outs)
 
@@ -290,8 +313,8 @@ def train_loss(sd, cfg, xs, ilens, ys, olens, ds, ps, es) -> Dict[str, float]:
     mean over the selected elements).  NOTE: the reference runs the padded batch through the
     FFT blocks, whose conv-FFN sees pad frames; for ragged batches this oracle follows the
     per-utterance (batch-1) semantics of SURVEY fact 6, as the product does."""
-    assert cfg["use_masking"] and cfg["postnet_layers"] == 0
-    l1_num = l1_den = 0.0
+    assert cfg["use_masking"]
+    l1_num = l1_den = lb_num = 0.0
     d_num = d_den = 0.0
     p_num = p_den = 0.0
     e_num = e_den = 0.0
@@ -306,13 +329,17 @@ def train_loss(sd, cfg, xs, ilens, ys, olens, ds, ps, es) -> Dict[str, float]:
             p_outs = variance_predict(hs_lr, sd, "pitch")
             e_outs = variance_predict(hs_lr, sd, "energy")
             hs_va = hs_lr + (variance_embed(ps[b, :ol], sd, "pitch") + variance_embed(es[b, :ol], sd, "energy"))
-            mel = decode(sd, cfg, hs_va)
+            before, mel = decode(sd, cfg, hs_va, return_before=True)
             l1_num += (mel - ys[b, :ol]).abs().sum().item(); l1_den += mel.numel()
+            lb_num += (before - ys[b, :ol]).abs().sum().item()
             tgt = torch.log(ds[b, :il].float() + DUR_OFFSET)
             d_num += ((logd - tgt) ** 2).sum().item(); d_den += il
             p_num += ((p_outs - ps[b, :ol]) ** 2).sum().item(); p_den += p_outs.numel()
             e_num += ((e_outs - es[b, :ol]) ** 2).sum().item(); e_den += e_outs.numel()
-    out = dict(l1_loss=l1_num / l1_den, duration_loss=d_num / d_den,
+    l1 = l1_num / l1_den
+    if cfg["postnet_layers"] != 0:              # network/fastspeech2.py:271-274
+        l1 += lb_num / l1_den
+    out = dict(l1_loss=l1, duration_loss=d_num / d_den,
                pitch_loss=p_num / p_den, energy_loss=e_num / e_den)
     out["loss"] = out["l1_loss"] + out["duration_loss"] + out["pitch_loss"] + out["energy_loss"]
     return out

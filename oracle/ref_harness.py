@@ -16,7 +16,10 @@ Repairs applied (numbers are SURVEY.md §0.1 rows; file:line are in /root/refere
   D5   DurationPredictor.linear on (B,C,T) (variance_adaptor.py:123,134)  -> transpose + squeeze(-1)
   D6   VarianceAdaptor.inference calls .forward (variance_adaptor.py:200) -> calls .inference
   D8   in-place `hs +=` (variance_adaptor.py:192) breaks backward         -> out-of-place (training only)
-D7 (PostNet) is not repaired: oracle configs use postnet_layers=0.
+  D7   PostNet builds n-1 layers, takes idim channels, never emits odim (fastspeech2.py:24-26,:161)
+       -> replaced by a repaired class (ESPnet layout: n conv layers k=filts bias=False, BatchNorm1d, tanh on
+          all but the last, first conv from odim, last conv to odim); the literal PostNet cannot run, so
+          parity for postnet_layers > 0 is pinned against THIS repaired definition only.
 D9 (fill_(1) on an all-zero duration row) is observable behaviour and is kept.
 """
 import os
@@ -162,6 +165,29 @@ def load():
         hs = hs + (pitch_embed + energy_embed)
         return hs, duration_outs, pitch_outs, energy_outs
     va.VarianceAdaptor.forward = _va_forward
+
+    # ---- D7 ---------------------------------------------------------------
+    class RepairedPostNet(nn.Module):
+        def __init__(self, in_dim, out_dim, n_layers=5, n_chans=512, n_filts=5, dropout_rate=0.5,
+                     use_batch_norm=True):
+            super().__init__()
+            self.postnet = nn.ModuleList()
+            for layer in range(n_layers):
+                ichans = out_dim if layer == 0 else n_chans          # the mel has odim channels, not idim
+                ochans = out_dim if layer == n_layers - 1 else n_chans
+                mods = [nn.Conv1d(ichans, ochans, n_filts, stride=1, padding=(n_filts - 1) // 2, bias=False)]
+                if use_batch_norm:
+                    mods.append(nn.BatchNorm1d(ochans))
+                if layer != n_layers - 1:
+                    mods.append(nn.Tanh())
+                mods.append(nn.Dropout(dropout_rate))
+                self.postnet.append(nn.Sequential(*mods))
+
+        def forward(self, xs):
+            for layer in self.postnet:
+                xs = layer(xs)
+            return xs
+    fs2.PostNet = RepairedPostNet
 
     ns = types.SimpleNamespace(enc=enc, va=va, fs2=fs2,
                                FeedForwardTransformer=fs2.FeedForwardTransformer)

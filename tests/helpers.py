@@ -12,8 +12,9 @@ from oracle import fs2_oracle
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 INFER_CASES = ["tiny_conv9_plain", "tiny_linear_scaled", "tiny_conv3_mixed_ln", "yaml_dims_2x2",
-               "d9_zero_durations", "duration_control_0p8", "duration_control_1p3", "baseline_4x4"]
-TRAIN_CASES = ["train_tiny_conv9", "train_tiny_linear"]
+               "d9_zero_durations", "duration_control_0p8", "duration_control_1p3", "baseline_4x4",
+               "postnet_tiny_bn", "postnet_tiny_nobn", "yaml_shipped_full"]
+TRAIN_CASES = ["train_tiny_conv9", "train_tiny_linear", "train_postnet_tiny"]
 
 
 def load_golden(name):

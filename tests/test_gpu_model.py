@@ -54,6 +54,8 @@ def test_fp32_matches_reference_golden(name):
         T = pk["olens"][i]
         assert np.abs(out["mel"][i, :T].cpu().numpy() - z["mel_%d" % i]).max() <= FP32_MEL_TOL
         assert (out["mel"][i, T:] == 0).all()
+        if "mel_before_%d" % i in z.files:      # (before_outs, after_outs) of _forward, network/fastspeech2.py:219-225
+            assert np.abs(pk["mel_before"].cpu().numpy()[cu_f[i]:cu_f[i + 1]] - z["mel_before_%d" % i]).max() <= FP32_MEL_TOL
         assert np.abs(pk["enc_out"].cpu().numpy()[cu_p[i]:cu_p[i + 1]] - z["enc_out_%d" % i]).max() <= 1e-3
         assert np.abs(pk["pitch"].cpu().numpy()[cu_f[i]:cu_f[i + 1]] - z["pitch_%d" % i]).max() <= 1e-3
         assert np.abs(pk["energy"].cpu().numpy()[cu_f[i]:cu_f[i + 1]] - z["energy_%d" % i]).max() <= 1e-3
@@ -61,7 +63,8 @@ def test_fp32_matches_reference_golden(name):
 
 # (the d=64 plain-PosEnc toy config is left out: its sqrt(d)-scaled embeddings and 64-wide LayerNorms
 #  amplify bf16 rounding to ~0.6 max-abs on a few frames; it is covered in fp32)
-@pytest.mark.parametrize("name", ["tiny_linear_scaled", "tiny_conv3_mixed_ln", "yaml_dims_2x2", "baseline_4x4"])
+@pytest.mark.parametrize("name", ["tiny_linear_scaled", "tiny_conv3_mixed_ln", "yaml_dims_2x2", "baseline_4x4",
+                                  "yaml_shipped_full"])
 def test_bf16_teacher_forced_durations(name):
     z, meta = helpers.load_golden(name)
     model = build_model(meta, "bf16")

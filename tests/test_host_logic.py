@@ -34,13 +34,14 @@ def test_yaml_loads_and_constructs():
     assert cfg["adim"] == 384 and cfg["postnet_layers"] == 5 and cfg["use_scaled_pos_enc"] is True
     ns = to_namespace_recursive({"a": {"b": 1}, "c": 2})
     assert ns.a.b == 1 and ns.c == 2
-    model = FeedForwardTransformer(80, 80, **cfg)          # shipped YAML constructs (D1 fixed)
+    model = FeedForwardTransformer(80, 80, **cfg)          # shipped YAML constructs (D1 fixed, PostNet repaired)
     assert model.encoder.embed[-1].alpha.item() == 1.0
-    with pytest.raises(NotImplementedError):                # ... but its PostNet cannot run (D7)
-        model.engine()
+    assert len(model.postnet.postnet) == 5 and model.postnet.postnet[0][0].in_channels == 80
+    assert model.postnet.postnet[4][0].out_channels == 80
 
 
-@pytest.mark.parametrize("name", ["tiny_conv9_plain", "tiny_linear_scaled", "tiny_conv3_mixed_ln", "baseline_4x4"])
+@pytest.mark.parametrize("name", ["tiny_conv9_plain", "tiny_linear_scaled", "tiny_conv3_mixed_ln", "baseline_4x4",
+                                  "postnet_tiny_bn", "postnet_tiny_nobn", "yaml_shipped_full"])
 def test_state_dict_layout_matches_spec(name):
     _, meta = helpers.load_golden(name)
     idim, odim, kw = helpers.split_cfg(meta["cfg"])

@@ -18,7 +18,7 @@ def test_oracle_matches_reference_inference(name):
     z, meta = helpers.load_golden(name)
     sd = helpers.golden_state_dict(meta)
     cfg = helpers.oracle_cfg(meta)
-    tol = MEL_TOL_BIG if name == "baseline_4x4" else MEL_TOL
+    tol = MEL_TOL_BIG if name in ("baseline_4x4", "yaml_shipped_full") else MEL_TOL
     for i in range(meta["n"]):
         x = torch.from_numpy(z["ids_%d" % i])
         out = fs2_oracle.infer_one(sd, cfg, x, duration_control=meta["duration_control"])
@@ -30,6 +30,8 @@ def test_oracle_matches_reference_inference(name):
         assert np.abs(out["pitch"].numpy() - z["pitch_%d" % i]).max() <= tol
         assert np.abs(out["energy"].numpy() - z["energy_%d" % i]).max() <= tol
         assert np.abs(out["mel"].numpy() - z["mel_%d" % i]).max() <= tol
+        if "mel_before_%d" % i in z.files:
+            assert np.abs(out["mel_before"].numpy() - z["mel_before_%d" % i]).max() <= tol
 
 
 @pytest.mark.parametrize("name", helpers.TRAIN_CASES)
