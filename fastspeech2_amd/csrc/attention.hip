@@ -5,8 +5,8 @@
 // Padded keys/queries do not exist in the packed layout, so the reference's mask fills
 // (:78-82) have nothing to act on; the key tail of the last tile is excluded with -inf.
 //
-// Work split: one workgroup (4 waves) per (utterance, head, 64-query tile); one wave per 16
-// queries.  K and V tiles of 64 keys are staged in LDS.  Orientation is chosen so that every
+// Work split: one workgroup (4 waves) per (utterance, head, 64*QT-query block); one wave per
+// 16*QT queries (QT = 2 for bf16, 1 for fp32).  K and V tiles of 64 keys are staged in LDS.  Orientation is chosen so that every
 // softmax statistic is lane-local:
 //   S^T = K . Q^T      mma(a = K rows, b = Q rows): lane (g,i) holds keys 4g..4g+3 of each
 //                       16-key tile for query i
