@@ -343,3 +343,42 @@ def train_loss(sd, cfg, xs, ilens, ys, olens, ds, ps, es) -> Dict[str, float]:
                pitch_loss=p_num / p_den, energy_loss=e_num / e_den)
     out["loss"] = out["l1_loss"] + out["duration_loss"] + out["pitch_loss"] + out["energy_loss"]
     return out
+
+
+def train_grads(sd, cfg, xs, ilens, ys, olens, ds, ps, es):
+    """Loss of `train_loss` with autograd through the functional restatement: returns
+    (loss terms, {parameter name: d loss / d parameter}).  What `loss.backward()` leaves in
+    `.grad` in run/train_decode.py:94-97 (accum_grad = 1), dropout off (eval-mode modules),
+    PostNet-free models only (training-mode BatchNorm statistics are not restated)."""
+    assert cfg["use_masking"] and cfg["postnet_layers"] == 0
+    leaf = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
+    B = len(ilens)
+    n_mel = sum(int(olens[b]) for b in range(B)) * cfg["odim"]
+    n_dur = sum(int(ilens[b]) for b in range(B))
+    n_fr = sum(int(olens[b]) for b in range(B))
+    terms = dict(l1_loss=0.0, duration_loss=0.0, pitch_loss=0.0, energy_loss=0.0)
+    total = 0.0
+    for b in range(B):
+        il, ol = int(ilens[b]), int(olens[b])
+        hs = encode(leaf, cfg, xs[b, :il])
+        logd = duration_log(hs, leaf)
+        idx, _ = length_regulate_index(ds[b, :il].numpy())
+        hs_lr = hs[torch.from_numpy(idx)]
+        p_outs = variance_predict(hs_lr, leaf, "pitch")
+        e_outs = variance_predict(hs_lr, leaf, "energy")
+        hs_va = hs_lr + (variance_embed(ps[b, :ol], leaf, "pitch") + variance_embed(es[b, :ol], leaf, "energy"))
+        mel = decode(leaf, cfg, hs_va)
+        tgt = torch.log(ds[b, :il].float() + DUR_OFFSET)
+        parts = dict(l1_loss=(mel - ys[b, :ol]).abs().sum() / n_mel,
+                     duration_loss=((logd - tgt) ** 2).sum() / n_dur,
+                     pitch_loss=((p_outs - ps[b, :ol]) ** 2).sum() / (n_fr * p_outs.shape[-1]),
+                     energy_loss=((e_outs - es[b, :ol]) ** 2).sum() / (n_fr * e_outs.shape[-1]))
+        loss_b = sum(parts.values())
+        loss_b.backward()                      # per utterance: keeps the graph small
+        for k, v in parts.items():
+            terms[k] += float(v.detach())
+        total += float(loss_b.detach())
+    terms["loss"] = total
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()
+             if v.dtype.is_floating_point}
+    return terms, grads

@@ -46,6 +46,7 @@ POSTNET_NOBN = dict(POSTNET_TINY, postnet_layers=2, postnet_chans=64, postnet_fi
 # the shipped param/fastspeech.yaml, all 37 keys as they are (6+6 linear-FFN blocks, d=384, 4 heads, postnet 5x256)
 YAML_SHIPPED = dict(idim=70, odim=80)
 BASELINE = dict(idim=80, odim=80, use_scaled_pos_enc=True, **synth.BASELINE_OVERRIDES)
+GRAD_SAMPLE = 1024
 
 
 def build(cfg, seed, dur_bias, alpha=1.0):
@@ -140,14 +141,33 @@ def run_train_case(name, cfg, seed, dur_bias, B, Tp, alpha=1.0):
             for d in dicts:
                 got.update(d)
     model.reporter = Spy()
-    with torch.no_grad():
+    extra = {}
+    grad_names = []
+    if cfg["postnet_layers"] == 0:
+        # gradients left by loss.backward() (run/train_decode.py:94-97; eval-mode modules = dropout off,
+        # repair D8): per parameter a strided sample of <= GRAD_SAMPLE elements plus (sum, l2 norm).
         loss = model.forward(torch.from_numpy(xs), torch.from_numpy(ilens), torch.from_numpy(ys),
                              torch.from_numpy(olens), torch.from_numpy(ds), torch.from_numpy(ps),
                              torch.from_numpy(es))
+        loss.backward()
+        stats = []
+        for j, (k, p) in enumerate(model.named_parameters()):
+            g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().reshape(-1).double()
+            step = max(1, -(-g.numel() // GRAD_SAMPLE))
+            extra["grad_%d" % j] = g[::step].float().numpy()
+            stats.append([float(g.sum()), float(g.norm())])
+            grad_names.append(k)
+        extra["grad_stats"] = np.array(stats, np.float64)
+    else:
+        with torch.no_grad():
+            loss = model.forward(torch.from_numpy(xs), torch.from_numpy(ilens), torch.from_numpy(ys),
+                                 torch.from_numpy(olens), torch.from_numpy(ds), torch.from_numpy(ps),
+                                 torch.from_numpy(es))
     meta = dict(name=name, cfg=cfg, seed=seed, dur_bias=dur_bias, alpha=alpha, torch=torch.__version__,
-                losses={k: float(v) for k, v in got.items()}, loss=float(loss))
+                losses={k: float(v) for k, v in got.items()}, loss=float(loss), grad_names=grad_names,
+                grad_sample=GRAD_SAMPLE)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), xs=xs, ilens=ilens, ys=ys, olens=olens,
-                        ds=ds, ps=ps, es=es, meta=np.array(json.dumps(meta)))
+                        ds=ds, ps=ps, es=es, meta=np.array(json.dumps(meta)), **extra)
     print("%-28s loss=%.6f %s" % (name, float(loss), {k: round(float(v), 5) for k, v in got.items()}))
 
 
@@ -169,6 +189,7 @@ def main():
     run_train_case("train_postnet_tiny", POSTNET_TINY, 15, math.log(3.0), B=2, Tp=11, alpha=0.9)
     run_train_case("train_tiny_conv9", TINY_A, 11, math.log(4.0), B=3, Tp=9)
     run_train_case("train_tiny_linear", TINY_B, 12, math.log(3.0), B=2, Tp=14, alpha=0.8)
+    run_train_case("train_tiny_conv3_mixed", TINY_C, 13, math.log(5.0), B=2, Tp=10, alpha=1.1)
 
 
 if __name__ == "__main__":

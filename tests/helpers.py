@@ -14,7 +14,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 INFER_CASES = ["tiny_conv9_plain", "tiny_linear_scaled", "tiny_conv3_mixed_ln", "yaml_dims_2x2",
                "d9_zero_durations", "duration_control_0p8", "duration_control_1p3", "baseline_4x4",
                "postnet_tiny_bn", "postnet_tiny_nobn", "yaml_shipped_full"]
-TRAIN_CASES = ["train_tiny_conv9", "train_tiny_linear", "train_postnet_tiny"]
+TRAIN_CASES = ["train_tiny_conv9", "train_tiny_linear", "train_postnet_tiny", "train_tiny_conv3_mixed"]
+GRAD_CASES = ["train_tiny_conv9", "train_tiny_linear", "train_tiny_conv3_mixed"]
 
 
 def load_golden(name):
@@ -44,3 +45,11 @@ def golden_state_dict(meta):
 def oracle_cfg(meta):
     idim, odim, kw = split_cfg(meta["cfg"])
     return fs2_oracle.full_cfg(idim, odim, **kw)
+
+
+def golden_grad_sample(z, meta, name, grad: torch.Tensor):
+    """(expected sample, got sample, expected (sum, l2)) for one parameter of a GRAD_CASES fixture."""
+    j = meta["grad_names"].index(name)
+    g = grad.detach().reshape(-1).double().cpu()
+    step = max(1, -(-g.numel() // meta["grad_sample"]))
+    return z["grad_%d" % j], g[::step].float().numpy(), z["grad_stats"][j], np.array([float(g.sum()), float(g.norm())])

@@ -45,6 +45,24 @@ def test_oracle_matches_reference_loss(name):
         assert abs(got[k] - meta["losses"][k]) <= 2e-5 * max(1.0, abs(meta["losses"][k])), k
 
 
+@pytest.mark.parametrize("name", helpers.GRAD_CASES)
+def test_oracle_gradients_match_reference_backward(name):
+    """d loss / d parameter of the restatement (autograd) vs what the repaired reference's
+    loss.backward() left in .grad; tolerance relative to the largest gradient entry of the tensor
+    (plus a floor for tensors whose true gradient is zero, e.g. linear_k.bias)."""
+    z, meta = helpers.load_golden(name)
+    sd = helpers.golden_state_dict(meta)
+    cfg = helpers.oracle_cfg(meta)
+    t = lambda k: torch.from_numpy(z[k])
+    _, grads = fs2_oracle.train_grads(sd, cfg, t("xs"), t("ilens"), t("ys"), t("olens"), t("ds"), t("ps"), t("es"))
+    assert sorted(grads) == sorted(meta["grad_names"])
+    for k in meta["grad_names"]:
+        want, got, wstat, gstat = helpers.golden_grad_sample(z, meta, k, grads[k])
+        tol = 1e-4 * max(np.abs(want).max(), 1e-2)
+        assert np.abs(want - got).max() <= tol, k
+        assert abs(wstat[1] - gstat[1]) <= 1e-4 * max(wstat[1], 1e-2), k
+
+
 def test_length_regulator_integer_rules():
     # zero-duration phones are skipped; an all-zero row becomes all ones (D9)
     idx, d = fs2_oracle.length_regulate_index(np.array([2, 0, 3, 1]))
