@@ -27,6 +27,8 @@ struct AttnArgs {
     const int* cu;       // [B+1] utterance row offsets
     int ld, ldo, d;      // d = h * dk
     float scale_log2e;   // log2(e) / sqrt(dk)
+    float* lse;          // [H][M] or null: log2-domain log-sum-exp of the scaled scores (saved for the backward)
+    int M;
 };
 
 typedef __attribute__((address_space(3))) void at_lds_void;
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
+        if (a.lse && g == 0 && qrow[t] < len) a.lse[(size_t)h * a.M + r0 + qrow[t]] = m_run[t] + __log2f(l);
         if (qrow[t] < len) {
             T* dst = (T*)a.ctx + (size_t)(r0 + qrow[t]) * a.ldo + h * DK;
 #pragma unroll
@@ -296,8 +299,8 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
 
 using namespace fs2;
 
-extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
-                             int ldo, int dtype, hipStream_t stream) {
+static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
+                           int dk, int ld, int ldo, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(qkv && ctx && cu && B > 0 && n_heads > 0, "fs2_attention: bad args");
     FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_attention: dtype=%d", dtype);
     FS2_CHECK_ARG(dk == 32 || dk == 64 || dk == 96 || dk == 128, "fs2_attention: head dim %d unsupported (32/64/96/128)",
@@ -308,7 +311,7 @@ extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, i
     FS2_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "fs2_attention: unaligned pointers");
     if (max_len <= 0) return FS2_OK;
     AttnArgs a;
-    a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d;
+    a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dk);
 #define FS2_ATT(TT, DKK) return launch_attention<TT, DKK>(a, B, n_heads, max_len, stream)
     if (dtype == 0) {
@@ -323,6 +326,18 @@ extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, i
         FS2_ATT(bf16_t, 128);
     }
 #undef FS2_ATT
+}
+
+extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
+                             int ldo, int dtype, hipStream_t stream) {
+    return attention_entry(qkv, ctx, nullptr, cu, B, max_len, 0, n_heads, dk, ld, ldo, dtype, stream);
+}
+
+// Training forward: as fs2_attention, and saves lse[h][m] (log2 domain, M = total rows) for fs2_attention_bwd.
+extern "C" int fs2_attention_fwd(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M,
+                                 int n_heads, int dk, int ld, int ldo, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(lse && M >= 0, "fs2_attention_fwd: null lse");
+    return attention_entry(qkv, ctx, lse, cu, B, max_len, M, n_heads, dk, ld, ldo, dtype, stream);
 }
 
 extern "C" int fs2_attention_dump(const void* qkv, float* atten, int row0, int len, int n_heads, int dk, int ld,

@@ -1,0 +1,447 @@
+// HBM-bound kernels of the training backward path (gfx950): LayerNorm backward fused with the
+// residual-gradient adds, column reductions (bias / LayerNorm-affine / tiny-head weight gradients),
+// LengthRegulator backward (segment sum), embedding backward, loss gradients and weight packing.
+// What autograd's backward of the reference modules computes (run/train_decode.py:94-97 calls
+// loss.backward() on network/fastspeech2.py:232-295) restated over the packed ragged layout.
+#include "common.h"
+
+namespace fs2 {
+
+constexpr int LNB_MAXV = 4;          // float4 per lane -> C <= 1024
+constexpr int LNB_ROWS = 32;         // rows per workgroup (4 waves x 8 rows)
+
+// g = dy + sum_p parts[p];  LayerNorm backward through x (statistics recomputed from x):
+//   xh = (x - mean) * rstd,  h = g * w,  dx = rstd * (h - mean(h) - xh * mean(h * xh))
+// (w == null: dx = g);  then dx += dres;  relu_gate: dx = x > 0 ? dx : 0 (x is a ReLU output).
+// Per-workgroup partial sums of d gamma = sum g * xh and d beta = sum g go to wb_part[blk][2][C].
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ parts, int nparts,
+                                                            long long part_stride, const float* __restrict__ w,
+                                                            const float* __restrict__ dres, int relu_gate,
+                                                            float* __restrict__ dx_f32, T* __restrict__ dx_t,
+                                                            float* __restrict__ wb_part, int M, int C, float eps) {
+    __shared__ float red[4][2][LNB_MAXV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cv = C >> 2;
+    f32x4 dgam[LNB_MAXV], dbet[LNB_MAXV];
+#pragma unroll
+    for (int k = 0; k < LNB_MAXV; ++k) dgam[k] = dbet[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float invC = 1.0f / (float)C;
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int row = blockIdx.x * LNB_ROWS + rr * 4 + wave;
+        if (row >= M) break;
+        const size_t roff = (size_t)row * C;
+        f32x4 xv[LNB_MAXV], gv[LNB_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LNB_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < cv) {
+                f32x4 t = dy ? *(const f32x4*)(dy + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+                gv[k] = t;
+                if (x) {
+                    xv[k] = *(const f32x4*)(x + roff + j * 4);
+                    s += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+                }
+            }
+        }
+        float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
+        if (w) {
+            mean = wave_sum(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNB_MAXV; ++k) {
+                const int j = lane + k * 64;
+                if (j < cv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dlt = xv[k][r] - mean;
+                        q += dlt * dlt;
+                    }
+                }
+            }
+            rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNB_MAXV; ++k) {
+                const int j = lane + k * 64;
+                if (j < cv) {
+                    const f32x4 ww = *(const f32x4*)(w + j * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (xv[k][r] - mean) * rstd;
+                        const float h = gv[k][r] * ww[r];
+                        a1 += h;
+                        a2 += h * xh;
+                        dgam[k][r] += gv[k][r] * xh;
+                        dbet[k][r] += gv[k][r];
+                    }
+                }
+            }
+            m1 = wave_sum(a1) * invC;
+            m2 = wave_sum(a2) * invC;
+        }
+#pragma unroll
+        for (int k = 0; k < LNB_MAXV; ++k) {
+            const int j = lane + k * 64;
+            if (j < cv) {
+                f32x4 o = gv[k];
+                if (w) {
+                    const f32x4 ww = *(const f32x4*)(w + j * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (xv[k][r] - mean) * rstd;
+                        o[r] = rstd * (gv[k][r] * ww[r] - m1 - xh * m2);
+                    }
+                }
+                if (dres) o += *(const f32x4*)(dres + roff + j * 4);
+                if (relu_gate) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = xv[k][r] > 0.f ? o[r] : 0.f;
+                }
+                if (dx_f32) *(f32x4*)(dx_f32 + roff + j * 4) = o;
+                if (dx_t) store4<T>(dx_t + roff + j * 4, o);
+            }
+        }
+    }
+    if (!wb_part) return;
+#pragma unroll
+    for (int k = 0; k < LNB_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            *(f32x4*)(&red[wave][0][j * 4]) = dgam[k];
+            *(f32x4*)(&red[wave][1][j * 4]) = dbet[k];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+        const int which = idx / C, c = idx % C;
+        const float t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        wb_part[(size_t)blockIdx.x * 2 * C + idx] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// column reductions, stage 1:  part[blk][r][c] = sum_{m in block} S[m][r] * G[m][c]  (S null: ones)
+// mode 1 (pe): S is ignored, part[blk][0][c] = sum_m G[m][c] * pe[pos[m]][c]  (d alpha of the scaled
+// positional encoding, network/encoder.py:142-145).  G is fp32 (g_is_t == 0) or T.
+// ---------------------------------------------------------------------------------------
+constexpr int CR_ROWS = 128;
+constexpr int CR_MAXR = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void colreduce_kernel(const void* __restrict__ Gv, int g_is_t, int ldg,
+                                                        const float* __restrict__ S, int lds_, int R,
+                                                        const float* __restrict__ pe, const int* __restrict__ pos,
+                                                        float* __restrict__ part, int M, int C) {
+    const int m0 = blockIdx.x * CR_ROWS;
+    const int m1 = min(M, m0 + CR_ROWS);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc[CR_MAXR];
+#pragma unroll
+        for (int r = 0; r < CR_MAXR; ++r) acc[r] = 0.f;
+        for (int m = m0; m < m1; ++m) {
+            const float gval = g_is_t ? to_f32(((const T*)Gv)[(size_t)m * ldg + c]) : ((const float*)Gv)[(size_t)m * ldg + c];
+            if (pe) {
+                acc[0] += gval * pe[(size_t)pos[m] * C + c];
+            } else if (S) {
+#pragma unroll
+                for (int r = 0; r < CR_MAXR; ++r)
+                    if (r < R) acc[r] += S[(size_t)m * lds_ + r] * gval;
+            } else {
+                acc[0] += gval;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < CR_MAXR; ++r)
+            if (r < R) part[((size_t)blockIdx.x * R + r) * C + c] = acc[r];
+    }
+}
+
+// stage 2: out[w] = scale * sum_blk part[blk * stride + w] (+ out[w])
+__global__ void colreduce_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int W,
+                                        long long stride, float scale, int accumulate) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * stride + w];
+    s *= scale;
+    out[w] = accumulate ? out[w] + s : s;
+}
+
+// dx[m, c] = sum_j dy[m, j] * W[j, c] — input gradient of the predictors' final nn.Linear
+__global__ void rowdot_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ W, float* __restrict__ dx,
+                                  int M, int C, int NOUT) {
+    const int cv = C >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * cv) return;
+    const int m = (int)(idx / cv), c = (int)(idx % cv) * 4;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NOUT; ++j) {
+        const float g = dy[(size_t)m * NOUT + j];
+        const f32x4 wv = *(const f32x4*)(W + (size_t)j * C + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += g * wv[r];
+    }
+    *(f32x4*)(dx + (size_t)m * C + c) = o;
+}
+
+// LengthRegulator backward: phone p receives the sum of the gradients of its frames (contiguous:
+// frames [cu_frames[b] + cum[p] - dur[p], cu_frames[b] + cum[p])), plus `base[p]` when given.
+__device__ __forceinline__ int find_segment_b(const int* __restrict__ cu, int B, int m) {
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= m) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void lr_scatter_kernel(const float* __restrict__ dframes, const int* __restrict__ dur,
+                                                         const int* __restrict__ cum, const int* __restrict__ cu_phone,
+                                                         const int* __restrict__ cu_frames, int B,
+                                                         const float* __restrict__ base, float scale,
+                                                         float* __restrict__ out, int Mp, int d) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= Mp) return;
+    const int b = find_segment_b(cu_phone, B, p);
+    const int n = dur[p];
+    const int f0 = cu_frames[b] + cum[p] - n;
+    const int dv = d >> 2;
+    for (int k = lane; k < dv; k += 64) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < n; ++f) s += *(const f32x4*)(dframes + (size_t)(f0 + f) * d + k * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] *= scale;
+        if (base) s += *(const f32x4*)(base + (size_t)p * d + k * 4);
+        *(f32x4*)(out + (size_t)p * d + k * 4) = s;
+    }
+}
+
+// Embedding backward: demb[v, :] = xscale * sum_{m : ids[m] == v} dx[m, :], row 0 (padding_idx) = 0.
+// One workgroup per vocabulary row; the id list is a few thousand entries.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dx,
+                                                        float xscale, float* __restrict__ demb, int M, int d, int idim,
+                                                        int accumulate) {
+    const int v = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        if (v != 0) {
+            for (int m = 0; m < M; ++m) {
+                long long id = ids[m];
+                id = id < 0 ? 0 : (id >= idim ? idim - 1 : id);
+                if (id == v) s += dx[(size_t)m * d + c];
+            }
+        }
+        s *= xscale;
+        float* dst = demb + (size_t)v * d + c;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+// loss gradients (network/fastspeech2.py:259-279, network/loss.py:5-14), scale = upstream / count:
+//   mode 0  L1  : g = scale * sign(pred - tgt)
+//   mode 1  MSE : g = 2 scale (pred - tgt)
+//   mode 2  duration MSE in the log domain: tgt = log(float(dur) + 1)
+// pred/tgt [M, C]; g_f32 [M, C] and/or g_t [M, ldt] (columns C..ldt-1 zero-filled).
+template <typename T>
+__global__ void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                 const int* __restrict__ dur, int mode, float scale, float* __restrict__ g_f32,
+                                 T* __restrict__ g_t, int M, int C, int ldt) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = g_t ? ldt : C;
+    if (idx >= (long long)M * W) return;
+    const int m = (int)(idx / W), c = (int)(idx % W);
+    float g = 0.f;
+    if (c < C) {
+        const float p = pred[(size_t)m * C + c];
+        const float t = mode == 2 ? logf((float)dur[(size_t)m * C + c] + 1.0f) : tgt[(size_t)m * C + c];
+        const float dlt = p - t;
+        g = mode == 0 ? (dlt > 0.f ? scale : (dlt < 0.f ? -scale : 0.f)) : 2.0f * scale * dlt;
+        if (g_f32) g_f32[(size_t)m * C + c] = g;
+    }
+    if (g_t) g_t[(size_t)m * ldt + c] = from_f32<T>(g);
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, float a, float* __restrict__ out, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = a * x[idx];
+}
+
+// Weight packing from the nn.Conv1d / nn.Linear parameter layout src (N, C, k) fp32:
+//   fwd[t][n][c]      = src[n][c][t]            (operand of the forward implicit GEMM, ld = ld_fwd)
+//   bwd[k-1-t][c][n]  = src[n][c][t]            (operand of the input-gradient GEMM: flipped taps,
+//                                                transposed channels, row length ld_bwd)
+// transposed == 0: threads run over (n, c) with c fastest (coalesced fwd writes);
+// transposed == 1: threads run over (c, n) with n fastest (coalesced bwd writes).
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ bwd, int N, int C,
+                                   int k, int ld_fwd, int ld_bwd, long long tap_stride_fwd, long long tap_stride_bwd,
+                                   int transposed) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * C) return;
+    int n, c;
+    if (transposed) { c = (int)(idx / N); n = (int)(idx % N); } else { n = (int)(idx / C); c = (int)(idx % C); }
+    const float* s = src + ((size_t)n * C + c) * k;
+    for (int t = 0; t < k; ++t) {
+        const T v = from_f32<T>(s[t]);
+        if (transposed)
+            bwd[(size_t)(k - 1 - t) * tap_stride_bwd + (size_t)c * ld_bwd + n] = v;
+        else
+            fwd[(size_t)t * tap_stride_fwd + (size_t)n * ld_fwd + c] = v;
+    }
+}
+
+}  // namespace fs2
+
+using namespace fs2;
+
+static inline int nblk(long long n, int per) { return (int)((n + per - 1) / per); }
+
+extern "C" long long fs2_layernorm_bwd_workspace(int M, int C) {
+    return (long long)nblk(M, LNB_ROWS) * 2 * C * (long long)sizeof(float);
+}
+
+extern "C" int fs2_layernorm_bwd(const float* x, const float* dy, const float* parts, int nparts, long long part_stride,
+                                 const float* w, const float* dres, int relu_gate, float* dx_f32, void* dx_t,
+                                 float* dw, float* db, float* workspace, int M, int C, float eps, int accumulate,
+                                 int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG((dy || nparts > 0) && (nparts == 0 || parts), "fs2_layernorm_bwd: no incoming gradient");
+    FS2_CHECK_ARG(dx_f32 || dx_t, "fs2_layernorm_bwd: nothing to write");
+    FS2_CHECK_ARG(!w || (x && dw && db && workspace), "fs2_layernorm_bwd: LayerNorm mode needs x, dw, db and a workspace");
+    FS2_CHECK_ARG(!relu_gate || x, "fs2_layernorm_bwd: relu_gate needs x");
+    FS2_CHECK_ARG(nparts >= 0 && nparts <= 16 && (nparts <= 1 || part_stride >= (long long)M * C),
+                  "fs2_layernorm_bwd: bad partial layout");
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LNB_MAXV, "fs2_layernorm_bwd: C=%d unsupported", C);
+    if (M <= 0) {
+        if (w && !accumulate) {
+            (void)hipMemsetAsync(dw, 0, C * sizeof(float), stream);
+            (void)hipMemsetAsync(db, 0, C * sizeof(float), stream);
+        }
+        return FS2_OK;
+    }
+    const int blocks = nblk(M, LNB_ROWS);
+    float* part = w ? workspace : nullptr;
+    if (dtype == 1)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, x, dy, parts, nparts,
+                           part_stride, w, dres, relu_gate, dx_f32, (bf16_t*)dx_t, part, M, C, eps);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, x, dy, parts, nparts,
+                           part_stride, w, dres, relu_gate, dx_f32, (float*)dx_t, part, M, C, eps);
+    FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
+    if (w) {
+        // part is [blocks][2][C]: gamma and beta sums finish in two strided passes
+        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 256)), dim3(256), 0, stream, part, dw, blocks, C,
+                           (long long)2 * C, 1.0f, accumulate);
+        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 256)), dim3(256), 0, stream, part + C, db, blocks, C,
+                           (long long)2 * C, 1.0f, accumulate);
+        FS2_CHECK_LAUNCH("fs2_layernorm_bwd(finish)");
+    }
+    return FS2_OK;
+}
+
+extern "C" long long fs2_colreduce_workspace(int M, int C, int R) {
+    return (long long)nblk(M > 0 ? M : 1, CR_ROWS) * R * C * (long long)sizeof(float);
+}
+
+extern "C" int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
+                             const int* pos, float* out, float* workspace, int M, int C, float scale, int accumulate,
+                             hipStream_t stream) {
+    FS2_CHECK_ARG(G && out && workspace, "fs2_colreduce: null pointer");
+    FS2_CHECK_ARG(g_dtype >= 0 && g_dtype <= 2, "fs2_colreduce: g_dtype=%d (0 fp32, 1 bf16)", g_dtype);
+    FS2_CHECK_ARG(R >= 1 && R <= CR_MAXR && (S || R == 1) && C > 0 && ldg >= C && (!S || lds >= R),
+                  "fs2_colreduce: R=%d (1..%d), C=%d, ldg=%d", R, CR_MAXR, C, ldg);
+    FS2_CHECK_ARG(!pe || (pos && R == 1), "fs2_colreduce: pe mode needs pos and R == 1");
+    const int blocks = nblk(M > 0 ? M : 1, CR_ROWS);
+    if (M <= 0) {
+        (void)hipMemsetAsync(workspace, 0, (size_t)R * C * sizeof(float), stream);
+    } else if (g_dtype == 1) {
+        hipLaunchKernelGGL(colreduce_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, G, 1, ldg, S, lds, R, pe, pos,
+                           workspace, M, C);
+    } else {
+        hipLaunchKernelGGL(colreduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, G, 0, ldg, S, lds, R, pe, pos,
+                           workspace, M, C);
+    }
+    hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk((long long)R * C, 256)), dim3(256), 0, stream, workspace, out,
+                       blocks, R * C, (long long)R * C, scale, accumulate);
+    FS2_CHECK_LAUNCH("fs2_colreduce");
+    return FS2_OK;
+}
+
+extern "C" int fs2_rowdot_bwd(const float* dy, const float* W, float* dx, int M, int C, int nout, hipStream_t stream) {
+    FS2_CHECK_ARG(dy && W && dx, "fs2_rowdot_bwd: null pointer");
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && nout >= 1 && nout <= 8, "fs2_rowdot_bwd: C=%d nout=%d unsupported", C, nout);
+    if (M <= 0) return FS2_OK;
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nblk((long long)M * (C / 4), 256)), dim3(256), 0, stream, dy, W, dx, M, C,
+                       nout);
+    FS2_CHECK_LAUNCH("fs2_rowdot_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_lr_scatter(const float* dframes, const int* dur, const int* cum, const int* cu_phone,
+                              const int* cu_frames, int B, const float* base, float scale, float* out, int Mp, int d,
+                              hipStream_t stream) {
+    FS2_CHECK_ARG(dframes && dur && cum && cu_phone && cu_frames && out && B > 0, "fs2_lr_scatter: bad args");
+    FS2_CHECK_ARG(d > 0 && d % 4 == 0, "fs2_lr_scatter: d=%d must be a multiple of 4", d);
+    if (Mp <= 0) return FS2_OK;
+    hipLaunchKernelGGL(lr_scatter_kernel, dim3(nblk(Mp, 4)), dim3(256), 0, stream, dframes, dur, cum, cu_phone, cu_frames,
+                       B, base, scale, out, Mp, d);
+    FS2_CHECK_LAUNCH("fs2_lr_scatter");
+    return FS2_OK;
+}
+
+extern "C" int fs2_embed_bwd(const long long* ids, const float* dx, float xscale, float* demb, int M, int d, int idim,
+                             int accumulate, hipStream_t stream) {
+    FS2_CHECK_ARG(ids && dx && demb && d > 0 && idim > 0 && M >= 0, "fs2_embed_bwd: bad args");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(idim), dim3(256), 0, stream, ids, dx, xscale, demb, M, d, idim, accumulate);
+    FS2_CHECK_LAUNCH("fs2_embed_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_loss_grad(const float* pred, const float* tgt, const int* dur, int mode, float scale, float* g_f32,
+                             void* g_t, int M, int C, int ldt, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(pred && (g_f32 || g_t) && mode >= 0 && mode <= 2, "fs2_loss_grad: bad args");
+    FS2_CHECK_ARG((mode == 2 && dur) || (mode != 2 && tgt), "fs2_loss_grad: missing target");
+    FS2_CHECK_ARG(C > 0 && (!g_t || ldt >= C), "fs2_loss_grad: ldt=%d < C=%d", ldt, C);
+    if (M <= 0) return FS2_OK;
+    const long long n = (long long)M * (g_t ? ldt : C);
+    if (dtype == 1)
+        hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, stream, pred, tgt, dur, mode, scale,
+                           g_f32, (bf16_t*)g_t, M, C, ldt);
+    else
+        hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, stream, pred, tgt, dur, mode, scale,
+                           g_f32, (float*)g_t, M, C, ldt);
+    FS2_CHECK_LAUNCH("fs2_loss_grad");
+    return FS2_OK;
+}
+
+extern "C" int fs2_scale(const float* x, float a, float* out, long long n, hipStream_t stream) {
+    FS2_CHECK_ARG(x && out && n >= 0, "fs2_scale: bad args");
+    if (n == 0) return FS2_OK;
+    hipLaunchKernelGGL(scale_kernel, dim3(nblk(n, 256)), dim3(256), 0, stream, x, a, out, n);
+    FS2_CHECK_LAUNCH("fs2_scale");
+    return FS2_OK;
+}
+
+extern "C" int fs2_pack_weight(const float* src, void* fwd, void* bwd, int N, int C, int k, int ld_fwd, int ld_bwd,
+                               long long tap_stride_fwd, long long tap_stride_bwd, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(src && (fwd || bwd) && N > 0 && C > 0 && k >= 1, "fs2_pack_weight: bad args");
+    FS2_CHECK_ARG((!fwd || (ld_fwd >= C && tap_stride_fwd >= (long long)(N - 1) * ld_fwd + C)) &&
+                      (!bwd || (ld_bwd >= N && tap_stride_bwd >= (long long)(C - 1) * ld_bwd + N)),
+                  "fs2_pack_weight: leading dimensions / tap strides too small");
+    const long long n = (long long)N * C;
+    for (int tr = 0; tr < 2; ++tr) {
+        if ((tr == 0 && !fwd) || (tr == 1 && !bwd)) continue;
+        if (dtype == 1)
+            hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, stream, src, (bf16_t*)fwd,
+                               (bf16_t*)bwd, N, C, k, ld_fwd, ld_bwd, tap_stride_fwd, tap_stride_bwd, tr);
+        else
+            hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, stream, src, (float*)fwd,
+                               (float*)bwd, N, C, k, ld_fwd, ld_bwd, tap_stride_fwd, tap_stride_bwd, tr);
+    }
+    FS2_CHECK_LAUNCH("fs2_pack_weight");
+    return FS2_OK;
+}

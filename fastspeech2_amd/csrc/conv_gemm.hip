@@ -36,6 +36,8 @@ struct ConvGemmArgs {
     const void* W;       // [taps][N][Cin] T
     const float* bias;   // [N] or null
     const float* res;    // [M, ldr] f32 or null
+    const void* gate;    // [M, ldg] T or null: out = gate > 0 ? out : 0 (ReLU backward through the saved activation)
+    int ldg;
     void* out;           // [M, ldo]  f32 (out_f32 != 0) or T
     const int2* seg;     // [M] (start,end) row range of the row's utterance; null when taps == 1
     int M, N, Cin, taps;
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     //      acc[mt][nt][r] <-> channel nb + 4 nt + r.  Loads are issued in batches (clamped
     //      addresses, predicated use) so their latencies overlap. ------------------------------
     const int nb = n0 + wn * (16 * NT) + g * (4 * NT);
-    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldo & 3) == 0) && (!a.res || (a.ldr & 3) == 0);
+    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldo & 3) == 0) && (!a.res || (a.ldr & 3) == 0) &&
+                        (!a.gate || (a.ldg & 3) == 0);
     if (vec_ok) {
         bool nok[NT];
         int ncl[NT];
@@ -342,6 +345,19 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[nt][r] = tanhf(v[nt][r]);
+            }
+            if (a.gate) {
+                const T* gp = (const T*)a.gate + mc * a.ldg;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    T g4[4];
+                    if constexpr (sizeof(T) == 2)
+                        *(uint2*)g4 = *(const uint2*)(gp + ncl[nt]);
+                    else
+                        *(f32x4*)g4 = *(const f32x4*)(gp + ncl[nt]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] = to_f32(g4[r]) > 0.f ? v[nt][r] : 0.f;
+                }
             }
             if (a.res) {
                 f32x4 rv[NT];
@@ -398,6 +414,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                     if (bias) s += bias[n];
                     if (a.relu == 1) s = fmaxf(s, 0.f);
                     if (a.relu == 2) s = tanhf(s);
+                    if (a.gate && !(to_f32(((const T*)a.gate)[(size_t)m * a.ldg + n]) > 0.f)) s = 0.f;
                     if (a.res) s += a.res[(size_t)m * a.ldr + n];
                     const size_t oidx = (size_t)blockIdx.y * a.split_stride + (size_t)m * a.ldo + n;
                     if (a.out_f32)
@@ -444,12 +461,13 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 }  // namespace fs2
 
 // dtype: 0 = f32, 1 = bf16 (include/fs2_hip.h)
-extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out,
-                             const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
-                             int relu /* activation: 0 none, 1 ReLU, 2 tanh */, int out_f32, int dtype, int ksplit,
-                             long long split_stride,
-                             hipStream_t stream) {
+static int conv_gemm_entry(const void* X, const void* W, const float* bias, const float* res, const void* gate,
+                           void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldg,
+                           int ldo, int relu, int out_f32, int dtype, int ksplit, long long split_stride,
+                           hipStream_t stream) {
     using namespace fs2;
+    FS2_CHECK_ARG(!gate || (ldg >= N && ((uintptr_t)gate & 15) == 0 && ksplit == 1),
+                  "fs2_conv_gemm_gated: gate needs ldg >= N, 16-byte alignment and ksplit == 1");
     FS2_CHECK_ARG(X && W && out, "fs2_conv_gemm: null X/W/out");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0, "fs2_conv_gemm: bad dims M=%d N=%d Cin=%d", M, N, Cin);
     FS2_CHECK_ARG(taps >= 1 && taps <= CG_MAX_TAPS && (taps & 1), "fs2_conv_gemm: taps=%d (odd, 1..%d)", taps,
@@ -469,9 +487,27 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
                   "fs2_conv_gemm: split-K partial outputs take no relu / residual and need split_stride >= M*ldo");
     if (M == 0) return FS2_OK;
     ConvGemmArgs a;
-    a.X = X; a.W = W; a.bias = bias; a.res = res; a.out = out; a.seg = (const int2*)seg;
+    a.X = X; a.W = W; a.bias = bias; a.res = res; a.gate = gate; a.ldg = ldg; a.out = out; a.seg = (const int2*)seg;
     a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.ldx = ldx; a.ldr = ldr; a.ldo = ldo;
     a.relu = relu; a.out_f32 = out_f32; a.n_tiles = 1;
     a.ksplit = ksplit; a.split_stride = ksplit > 1 ? split_stride : 0;
     return dtype == 0 ? dispatch_conv_gemm<float>(a, stream) : dispatch_conv_gemm<bf16_t>(a, stream);
+}
+
+extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out,
+                             const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
+                             int relu /* activation: 0 none, 1 ReLU, 2 tanh */, int out_f32, int dtype, int ksplit,
+                             long long split_stride, hipStream_t stream) {
+    return conv_gemm_entry(X, W, bias, res, nullptr, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, out_f32, dtype,
+                           ksplit, split_stride, stream);
+}
+
+// Input gradient of a conv / linear whose input was a ReLU output: the same implicit GEMM over the
+// flipped, transposed weights, with the ReLU derivative applied from the saved activation `gate`.
+extern "C" int fs2_conv_gemm_gated(const void* X, const void* W, const float* bias, const float* res, const void* gate,
+                                   void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldg,
+                                   int ldo, int out_f32, int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(gate, "fs2_conv_gemm_gated: null gate");
+    return conv_gemm_entry(X, W, bias, res, gate, out, seg, M, N, Cin, taps, ldx, ldr, ldg, ldo, 0, out_f32, dtype, 1, 0,
+                           stream);
 }

@@ -41,8 +41,27 @@ _SIGNATURES = {
     "fs2_unpack_padded": [_P, _P, _P, _I, _I, _I, _P],
     "fs2_pack_padded": [_P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _P, _L, _I, _P],
+    # training path
+    "fs2_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_conv_gemm_gated": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_conv_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "fs2_layernorm_bwd": [_P, _P, _P, _I, _L, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _P],
+    "fs2_colreduce": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "fs2_rowdot_bwd": [_P, _P, _P, _I, _I, _I, _P],
+    "fs2_lr_scatter": [_P, _P, _P, _P, _P, _I, _P, _F, _P, _I, _I, _P],
+    "fs2_embed_bwd": [_P, _P, _F, _P, _I, _I, _I, _I, _P],
+    "fs2_loss_grad": [_P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_scale": [_P, _F, _P, _L, _P],
+    "fs2_pack_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _P],
 }
-EXPORTS = sorted(list(_SIGNATURES) + ["fs2_last_error", "fs2_abi_version", "fs2_device_arch"])
+# workspace-size queries (return bytes as long long, no launch)
+_SIZE_QUERIES = {
+    "fs2_conv_wgrad_workspace": [_I, _I, _I, _I],
+    "fs2_layernorm_bwd_workspace": [_I, _I],
+    "fs2_colreduce_workspace": [_I, _I, _I],
+}
+EXPORTS = sorted(list(_SIGNATURES) + list(_SIZE_QUERIES) + ["fs2_last_error", "fs2_abi_version", "fs2_device_arch"])
 
 
 def lib_path() -> str:
@@ -63,6 +82,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_int
+    for name, argtypes in _SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_longlong
     lib.fs2_last_error.restype = c_char_p
     lib.fs2_abi_version.restype = c_int
     lib.fs2_device_arch.argtypes = [c_char_p, c_int]

@@ -126,6 +126,86 @@ int fs2_pack_padded(const float* src, const int* cu, float* dst, int B, int Tmax
 /* fp32 -> T copy (weight packing). */
 int fs2_cast(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training path: what loss.backward() (run/train_decode.py:94-97) computes through the modules of
+ * network/encoder.py, network/variance_adaptor.py and network/fastspeech2.py:232-295, restated
+ * over the packed layout.  Gradients of GEMM operands travel as T matrices, the residual-stream
+ * gradient and every parameter gradient as fp32.  `accumulate` != 0 adds into the output
+ * (gradient accumulation, run/train_decode.py:94-102).
+ * ------------------------------------------------------------------------------------------ */
+
+/* fs2_attention that also saves lse[h][m] (log2-domain log-sum-exp of the scaled scores,
+ * [n_heads][M] fp32, M = total packed rows) for fs2_attention_bwd. */
+int fs2_attention_fwd(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
+                      int dk, int ld, int ldo, int dtype, hipStream_t stream);
+
+/* Backward of MultiHeadedAttention's core (network/encoder.py:73-88): from qkv, ctx (forward output),
+ * dctx and lse computes dqkv [M, ld] T (dq | dk | dv).  delta: fp32 scratch [n_heads][M].
+ * Probabilities are recomputed per tile; every output element has one writer (deterministic). */
+int fs2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv,
+                      const int* cu, int B, int max_len, int M, int n_heads, int dk, int ld, int ldo, int dtype,
+                      hipStream_t stream);
+
+/* fs2_conv_gemm (no activation, no split-K) whose result is zeroed where gate[m, n] <= 0: the input
+ * gradient of a conv / linear fed by a ReLU (`torch.relu(self.w1(x))`, network/encoder.py:29, :43),
+ * computed as the same implicit GEMM over the flipped-transposed weights (fs2_pack_weight `bwd`). */
+int fs2_conv_gemm_gated(const void* X, const void* W, const float* bias, const float* res, const void* gate, void* out,
+                        const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldg, int ldo, int out_f32,
+                        int dtype, hipStream_t stream);
+
+/* Weight gradient of nn.Conv1d / nn.Linear (same layers as fs2_conv_gemm):
+ *   grad[n][c][tap] (the parameter's own layout, fp32) = scale * sum_m dY[m, n] * X[m + tap - pad, c]
+ * over token pairs inside one utterance.  MFMA GEMM over the token axis, `ksplit` token ranges
+ * summed in a fixed order from `workspace` (fs2_conv_wgrad_workspace bytes). */
+long long fs2_conv_wgrad_workspace(int N, int Cin, int taps, int ksplit);
+int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float* workspace, const int* seg, int M, int N, int Cin,
+                   int taps, int ldy, int ldx, int dtype, int ksplit, float scale, int accumulate, hipStream_t stream);
+
+/* LayerNorm backward (network/utils.py:39-47) fused with the residual-gradient adds of
+ * EncoderLayer.forward (network/encoder.py:171-187):  g = dy + sum_p parts[p];
+ * dx = LayerNormBackward(g; x, w) (w == NULL: dx = g) + dres; relu_gate != 0 additionally zeroes dx
+ * where x <= 0 (x is the ReLU output feeding the predictors' LayerNorm, network/variance_adaptor.py:66-75).
+ * dw / db receive the affine gradients.  workspace: fs2_layernorm_bwd_workspace bytes. */
+long long fs2_layernorm_bwd_workspace(int M, int C);
+int fs2_layernorm_bwd(const float* x, const float* dy, const float* parts, int nparts, long long part_stride,
+                      const float* w, const float* dres, int relu_gate, float* dx_f32, void* dx_t, float* dw, float* db,
+                      float* workspace, int M, int C, float eps, int accumulate, int dtype, hipStream_t stream);
+
+/* out[r][c] = scale * sum_m S[m][r] * G[m][c]  (S NULL: column sums, R = 1) — bias gradients, the
+ * predictors' final-Linear and the k=1 VarianceEmbedding weight gradients.  pe != NULL:
+ * out[c] = scale * sum_m G[m][c] * pe[pos[m]][c] (d alpha of ScaledPositionalEncoding summed over c
+ * by the caller, network/encoder.py:142-145).  G fp32 (g_dtype 0) or bf16 (1).  R <= 8.
+ * workspace: fs2_colreduce_workspace bytes. */
+long long fs2_colreduce_workspace(int M, int C, int R);
+int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe, const int* pos,
+                  float* out, float* workspace, int M, int C, float scale, int accumulate, hipStream_t stream);
+
+/* dx[m, :] = sum_j dy[m, j] * W[j, :] — input gradient of fs2_rowdot. */
+int fs2_rowdot_bwd(const float* dy, const float* W, float* dx, int M, int C, int nout, hipStream_t stream);
+
+/* LengthRegulator backward (network/variance_adaptor.py:13-31): out[p, :] = base[p, :] (or 0) +
+ * scale * sum of dframes over the dur[p] frames phone p was repeated into. */
+int fs2_lr_scatter(const float* dframes, const int* dur, const int* cum, const int* cu_phone, const int* cu_frames, int B,
+                   const float* base, float scale, float* out, int Mp, int d, hipStream_t stream);
+
+/* nn.Embedding(padding_idx=0) backward: demb[v, :] = xscale * sum_{m: ids[m] == v} dx[m, :], row 0 zero. */
+int fs2_embed_bwd(const long long* ids, const float* dx, float xscale, float* demb, int M, int d, int idim,
+                  int accumulate, hipStream_t stream);
+
+/* Loss gradients (network/fastspeech2.py:259-279, network/loss.py:5-14): mode 0 L1, 1 MSE, 2 MSE against
+ * log(dur + 1); scale = upstream gradient / element count.  Writes fp32 [M, C] and/or T [M, ldt]
+ * (pad columns zero-filled so the matrix can feed the MFMA kernels). */
+int fs2_loss_grad(const float* pred, const float* tgt, const int* dur, int mode, float scale, float* g_f32, void* g_t,
+                  int M, int C, int ldt, int dtype, hipStream_t stream);
+
+/* out = a * x (fp32). */
+int fs2_scale(const float* x, float a, float* out, long long n, hipStream_t stream);
+
+/* Packs a parameter in nn.Conv1d / nn.Linear layout src (N, C, k) fp32 into the GEMM operand layouts:
+ * fwd[t][n][c] (fs2_conv_gemm) and bwd[k-1-t][c][n] (input gradient); either may be NULL. */
+int fs2_pack_weight(const float* src, void* fwd, void* bwd, int N, int C, int k, int ld_fwd, int ld_bwd,
+                    long long tap_stride_fwd, long long tap_stride_bwd, int dtype, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
