@@ -249,9 +249,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
 // pred/tgt [M, C]; g_f32 [M, C] and/or g_t [M, ldt] (columns C..ldt-1 zero-filled).
 template <typename T>
 __global__ void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
-                                 const int* __restrict__ dur, int mode, float scale, float* __restrict__ g_f32,
-                                 T* __restrict__ g_t, int M, int C, int ldt) {
+                                 const int* __restrict__ dur, int mode, float scale,
+                                 const float* __restrict__ scale_dev, float* __restrict__ g_f32, T* __restrict__ g_t,
+                                 int M, int C, int ldt) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (scale_dev) scale *= *scale_dev;
     const int W = g_t ? ldt : C;
     if (idx >= (long long)M * W) return;
     const int m = (int)(idx / W), c = (int)(idx % W);
@@ -401,8 +403,9 @@ extern "C" int fs2_embed_bwd(const long long* ids, const float* dx, float xscale
     return FS2_OK;
 }
 
-extern "C" int fs2_loss_grad(const float* pred, const float* tgt, const int* dur, int mode, float scale, float* g_f32,
-                             void* g_t, int M, int C, int ldt, int dtype, hipStream_t stream) {
+extern "C" int fs2_loss_grad(const float* pred, const float* tgt, const int* dur, int mode, float scale,
+                             const float* scale_dev, float* g_f32, void* g_t, int M, int C, int ldt, int dtype,
+                             hipStream_t stream) {
     FS2_CHECK_ARG(pred && (g_f32 || g_t) && mode >= 0 && mode <= 2, "fs2_loss_grad: bad args");
     FS2_CHECK_ARG((mode == 2 && dur) || (mode != 2 && tgt), "fs2_loss_grad: missing target");
     FS2_CHECK_ARG(C > 0 && (!g_t || ldt >= C), "fs2_loss_grad: ldt=%d < C=%d", ldt, C);
@@ -410,10 +413,10 @@ extern "C" int fs2_loss_grad(const float* pred, const float* tgt, const int* dur
     const long long n = (long long)M * (g_t ? ldt : C);
     if (dtype == 1)
         hipLaunchKernelGGL(loss_grad_kernel<bf16_t>, dim3(nblk(n, 256)), dim3(256), 0, stream, pred, tgt, dur, mode, scale,
-                           g_f32, (bf16_t*)g_t, M, C, ldt);
+                           scale_dev, g_f32, (bf16_t*)g_t, M, C, ldt);
     else
         hipLaunchKernelGGL(loss_grad_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, stream, pred, tgt, dur, mode, scale,
-                           g_f32, (float*)g_t, M, C, ldt);
+                           scale_dev, g_f32, (float*)g_t, M, C, ldt);
     FS2_CHECK_LAUNCH("fs2_loss_grad");
     return FS2_OK;
 }

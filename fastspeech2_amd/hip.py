@@ -51,7 +51,7 @@ _SIGNATURES = {
     "fs2_rowdot_bwd": [_P, _P, _P, _I, _I, _I, _P],
     "fs2_lr_scatter": [_P, _P, _P, _P, _P, _I, _P, _F, _P, _I, _I, _P],
     "fs2_embed_bwd": [_P, _P, _F, _P, _I, _I, _I, _I, _P],
-    "fs2_loss_grad": [_P, _P, _P, _I, _F, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_loss_grad": [_P, _P, _P, _I, _F, _P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_scale": [_P, _F, _P, _L, _P],
     "fs2_pack_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _P],
 }

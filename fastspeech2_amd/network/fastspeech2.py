@@ -111,6 +111,36 @@ def _postnet(odim, n_layers, chans, filts, use_batch_norm, dropout):
     return pn
 
 
+class _TrainStep(torch.autograd.Function):
+    """One autograd node for the whole teacher-forced step: forward and backward are explicit HIP
+    launch schedules (fastspeech2_amd/train_engine.py); the parameters are its differentiable inputs."""
+
+    @staticmethod
+    def forward(ctx, model, eng, batch, names, *params):
+        ids, il, ol, ds_p, ps_p, es_p, ys_p = batch
+        outs, saved = eng.forward(ids, il, ol, ds_p, ps_p, es_p, ys_p)
+        l1_loss = F.l1_loss(outs["before"], ys_p)                              # network/fastspeech2.py:271-274
+        duration_loss = model.duration_criterion(outs["log_durations"], ds_p)  # network/loss.py:5-14
+        pitch_loss = model.mse_criterion(outs["pitch"], ps_p)
+        energy_loss = model.mse_criterion(outs["energy"], es_p)
+        loss = l1_loss + duration_loss + pitch_loss + energy_loss
+        report_keys = [{"l1_loss": l1_loss}, {"duration_loss": duration_loss}, {"pitch_loss": pitch_loss},
+                       {"energy_loss": energy_loss}, {"loss": loss.detach()}]
+        if model.use_scaled_pos_enc:
+            report_keys += [{"encoder_alpha": model.encoder.embed[-1].alpha.data},
+                            {"decoder_alpha": model.decoder.embed[-1].alpha.data}]
+        model.reporter.report(report_keys)
+        ctx.eng, ctx.saved, ctx.names = eng, saved, names
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        up = grad_loss.detach().reshape(1).to(torch.float32).contiguous()
+        G = ctx.eng.backward(ctx.saved, up)
+        ctx.saved = None
+        return (None, None, None, None) + tuple(G[n] for n in ctx.names)
+
+
 class FeedForwardTransformer(nn.Module):
     def __init__(self,
                  idim: int,
@@ -284,14 +314,48 @@ class FeedForwardTransformer(nn.Module):
         cu = np.concatenate([[0], np.cumsum(lens)])
         return [int(v[cu[i]:cu[i + 1]].sum()) for i in range(len(lens))]
 
+    def train_engine(self):
+        """Training-step launch schedule (forward + backward kernels) bound to this module's parameters."""
+        from ..train_engine import TrainEngine
+        key = (self._precision[0], tuple(p.data_ptr() for p in self.parameters()))
+        if getattr(self, "_train_engine", None) is None or self._train_engine_key != key:
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                from ..hip import HipError
+                raise HipError("model parameters are on %s: move the model to the MI355X (`model.cuda()`); the "
+                               "training path has no CPU implementation" % dev)
+            self._train_engine = TrainEngine(self, dtype=self._precision[0])
+            self._train_engine_key = key
+        return self._train_engine
+
+    def _forward_train(self, xs, ilens, ys, olens, ds, ps, es):
+        """Teacher-forced step with a backward: the loss tensor is the output of one autograd node whose
+        backward runs the HIP backward schedule and hands every parameter its gradient, so the reference's
+        `loss.backward(); clip_grad_norm_; optimizer.step()` (run/train_decode.py:94-110) works unchanged."""
+        eng = self.train_engine()
+        il, ol = [int(v) for v in ilens], [int(v) for v in olens]
+        dev = eng.dev
+        ids = self._pack(xs.to(dev), il).to(torch.int64).contiguous()
+        ds_p = self._pack(ds.to(dev), il).to(torch.int32).contiguous()
+        if [int(v) for v in self._segment_sums(ds_p, il)] != ol:
+            raise ValueError("sum(ds) per utterance must equal olens")
+        ys_p = self._pack(ys.to(dev), ol).float().contiguous()
+        ps_p = self._pack(ps.to(dev), ol).float().contiguous()
+        es_p = self._pack(es.to(dev), ol).float().contiguous()
+        names = list(eng.P)
+        return _TrainStep.apply(self, eng, (ids, il, ol, ds_p, ps_p, es_p, ys_p), names, *[eng.P[n] for n in names])
+
     def forward(self, xs, ilens, ys, olens, ds, ps, es, **_ignored):
         """Loss of one teacher-forced step (network/fastspeech2.py:232-295).  Extra keys produced by
         the reference's converter (`labels`, `spkids`, run/train_decode.py:136-149) are ignored.
-        The value is computed by the HIP forward kernels; it carries no autograd graph (backward
-        kernels are outside this round — SURVEY.md §7 step 7)."""
+        In training mode with grad enabled the returned loss carries a backward (HIP kernels, see
+        `_forward_train`); under `torch.no_grad()` / `eval()` it is the plain value (evaluator path,
+        run/train_decode.py:42-57).  Dropout is never applied."""
         il, ol = [int(v) for v in ilens], [int(v) for v in olens]
         xs, ds = xs[:, :max(il)], ds[:, :max(il)]
         ys, ps, es = ys[:, :max(ol)], ps[:, :max(ol)], es[:, :max(ol)]
+        if self.training and torch.is_grad_enabled() and self.postnet is None:
+            return self._forward_train(xs, ilens, ys, olens, ds, ps, es)
         _, _, out = self._forward(xs, ilens, olens, ds, ps, es, is_inference=False, _raw=True)
         dev = out["mel"].device
         if not self.use_masking:

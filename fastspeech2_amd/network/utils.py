@@ -67,8 +67,14 @@ class Reporter:
     observation as a plain dict (chainer is not a dependency of this package)."""
 
     def __init__(self):
-        self.observation = {}
+        self._raw = {}
 
     def report(self, dicts):
+        """Values may be floats or 0-dim device tensors; tensors are read back only when
+        `observation` is looked at, so a training step enqueues without a host sync."""
         for d in dicts:
-            self.observation.update(d)
+            self._raw.update(d)
+
+    @property
+    def observation(self):
+        return {k: (float(v) if not isinstance(v, float) else v) for k, v in self._raw.items()}

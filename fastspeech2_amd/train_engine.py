@@ -1,0 +1,634 @@
+"""Launch schedule of one teacher-forced training step (forward + backward) on the gfx950 kernels.
+
+Forward follows `FeedForwardTransformer.forward` / `_forward` (network/fastspeech2.py:187-295) and
+`VarianceAdaptor.forward` (network/variance_adaptor.py:178-193, repair D8); backward is what
+`loss.backward()` (run/train_decode.py:94-97) computes through those modules, written out as an
+explicit sequence of C-ABI launches (include/fs2_hip.h "Training path").  Dropout is not applied
+(the step is deterministic; rates must be regarded as 0 — DESIGN.md §7).
+
+Weights stay in the model's fp32 `nn.Parameter`s (the optimiser's master copy).  Every step the
+GEMM operands are re-packed from them by `fs2_pack_weight` into persistent buffers: `fwd`
+([tap][N][C], forward and weight-gradient layout) and `bwd` ([tap][C][N], flipped taps: the operand of
+the input-gradient GEMM).  Parameter gradients are written (fp32, the parameters' own layouts) into
+one flat buffer laid out in the order the backward finishes them, so data-parallel training can
+all-reduce contiguous buckets while the rest of the backward is still running (`grad_ready` hook).
+"""
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip
+from .engine import LN_EPS, posenc_table
+from .hip import BF16, F32, call, ptr, stream
+
+
+class _Weight:
+    """One GEMM weight: parameter(s) in reference layout -> packed fwd / bwd operands."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], tdt, dev, pad_n: int = 0):
+        p0 = params[0]
+        self.params = list(params)
+        self.k = p0.shape[2] if p0.dim() == 3 else 1
+        self.n_each = p0.shape[0]
+        self.N = self.n_each * len(params)
+        self.C = p0.shape[1]
+        self.Np = max(self.N, pad_n)             # row length of the bwd operand (zero padded)
+        self.fwd = torch.zeros((self.k, self.N, self.C), device=dev, dtype=tdt)
+        self.bwd = torch.zeros((self.k, self.C, self.Np), device=dev, dtype=tdt)
+
+    def pack(self, code):
+        for j, p in enumerate(self.params):
+            esz = self.fwd.element_size()
+            f = self.fwd.data_ptr() + j * self.n_each * self.C * esz
+            b = self.bwd.data_ptr() + j * self.n_each * esz
+            call("fs2_pack_weight", ptr(p.data), hip.c_void_p(f), hip.c_void_p(b), self.n_each, self.C, self.k, self.C,
+                 self.Np, self.N * self.C, self.C * self.Np, code, stream())
+
+
+class TrainEngine:
+    def __init__(self, model, dtype: str = "fp32"):
+        self.dev = hip.require_gpu()
+        hip.load()
+        self.model = model
+        cfg = model.cfg
+        self.cfg = cfg
+        self.code = hip.DTYPE_CODE[dtype]
+        self.tdt = hip.TORCH_DTYPE[self.code]
+        self.epv = 4 if self.code == F32 else 8
+        d = cfg["adim"]
+        self.d, self.h = d, cfg["aheads"]
+        self.dk = d // self.h
+        if self.dk not in (32, 64, 96, 128):
+            raise NotImplementedError("head dim %d: the attention kernels support 32/64/96/128" % self.dk)
+        if cfg["postnet_layers"] != 0:
+            raise NotImplementedError("training with a PostNet (training-mode BatchNorm) is not built: "
+                                      "set postnet_layers=0")
+        if cfg["reduction_factor"] != 1:
+            raise NotImplementedError("reduction_factor != 1")
+        if not cfg["use_masking"]:
+            raise NotImplementedError("use_masking=False")
+        self.P: Dict[str, torch.nn.Parameter] = dict(model.named_parameters())
+        for k, p in self.P.items():
+            if p.device != self.dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise hip.HipError("parameter %s must be a contiguous fp32 tensor on %s" % (k, self.dev))
+        self.scaled = cfg["use_scaled_pos_enc"]
+        self.ff_conv = cfg["positionwise_layer_type"] == "conv1d"
+        self.odim = cfg["odim"]
+        self.idim = cfg["idim"]
+        self.odim_pad = -(-self.odim // self.epv) * self.epv
+        self._build_weights()
+        self._build_grad_buffer()
+        self._pe = None
+        self.grad_ready: Optional[Callable[[int], None]] = None   # called with the index of a finished bucket
+        self.profile = None
+
+    # ------------------------------------------------------------------ set-up
+    def _stack_weights(self, prefix, n_layers, concat_after):
+        P, tdt, dev = self.P, self.tdt, self.dev
+        layers = []
+        for i in range(n_layers):
+            p = "%sencoders.%d." % (prefix, i)
+            L = dict(prefix=p)
+            L["wqkv"] = _Weight([P[p + "self_atten.linear_%s.weight" % n] for n in "qkv"], tdt, dev)
+            L["wo"] = _Weight([P[p + "self_atten.linear_out.weight"]], tdt, dev)
+            L["w1"] = _Weight([P[p + "feed_forward.w1.weight"]], tdt, dev)
+            L["w2"] = _Weight([P[p + "feed_forward.w2.weight"]], tdt, dev)
+            L["bqkv"] = torch.empty((3 * self.d,), device=dev)
+            if concat_after:
+                L["wc_x"] = _Weight([torch.nn.Parameter(P[p + "concat_linear.weight"][:, :self.d].contiguous())], tdt, dev)
+                L["wc_a"] = _Weight([torch.nn.Parameter(P[p + "concat_linear.weight"][:, self.d:].contiguous())], tdt, dev)
+            layers.append(L)
+        return layers
+
+    def _pred_weights(self, prefix):
+        convs, j = [], 0
+        while "%sconv.%d.0.conv.weight" % (prefix, j) in self.P:
+            convs.append(dict(w=_Weight([self.P["%sconv.%d.0.conv.weight" % (prefix, j)]], self.tdt, self.dev),
+                              p="%sconv.%d." % (prefix, j)))
+            j += 1
+        return dict(prefix=prefix, convs=convs, nout=self.P[prefix + "linear.weight"].shape[0])
+
+    def _build_weights(self):
+        cfg = self.cfg
+        self.enc_layers = self._stack_weights("encoder.", cfg["elayers"], cfg["encoder_concat_after"])
+        self.dec_layers = self._stack_weights("decoder.", cfg["dlayers"], cfg["decoder_concat_after"])
+        va = "variance_adaptor."
+        self.dur_pred = self._pred_weights(va + "duration_predictor.")
+        self.pitch_pred = self._pred_weights(va + "pitch_predictor.")
+        self.energy_pred = self._pred_weights(va + "energy_predictor.")
+        self.w_out = _Weight([self.P["feat_out.weight"]], self.tdt, self.dev, pad_n=self.odim_pad)
+        wp, we = self.P[va + "pitch_embed.conv.conv.weight"], self.P[va + "energy_embed.conv.conv.weight"]
+        if wp.shape[-1] != 1 or we.shape[-1] != 1:
+            raise NotImplementedError("pitch/energy embed kernel size must be 1")
+        self.pdim, self.edim = wp.shape[1], we.shape[1]
+
+    def _all_weights(self) -> List[_Weight]:
+        out = [self.w_out]
+        for L in self.enc_layers + self.dec_layers:
+            out += [L[k] for k in ("wqkv", "wo", "w1", "w2", "wc_x", "wc_a") if k in L]
+        for pr in (self.dur_pred, self.pitch_pred, self.energy_pred):
+            out += [c["w"] for c in pr["convs"]]
+        return out
+
+    def _layer_param_names(self, L, concat_after):
+        p = L["prefix"]
+        names = [p + "self_atten.linear_%s.weight" % n for n in "qkv"]      # adjacent: one fused gradient GEMM
+        names += [p + "self_atten.linear_%s.bias" % n for n in "qkv"]
+        names += [p + "self_atten.linear_out.weight", p + "self_atten.linear_out.bias",
+                  p + "feed_forward.w1.weight", p + "feed_forward.w1.bias",
+                  p + "feed_forward.w2.weight", p + "feed_forward.w2.bias",
+                  p + "norm1.weight", p + "norm1.bias", p + "norm2.weight", p + "norm2.bias"]
+        if concat_after:
+            names += [p + "concat_linear.weight", p + "concat_linear.bias"]
+        return names
+
+    def _pred_param_names(self, pr):
+        names = [pr["prefix"] + "linear.weight", pr["prefix"] + "linear.bias"]
+        for c in pr["convs"]:
+            names += [c["p"] + "0.conv.weight", c["p"] + "0.conv.bias", c["p"] + "2.weight", c["p"] + "2.bias"]
+        return names
+
+    def _build_grad_buffer(self):
+        """Flat fp32 gradient buffer, bucketed in backward-completion order."""
+        cfg = self.cfg
+        va = "variance_adaptor."
+        buckets: List[List[str]] = [["feat_out.weight", "feat_out.bias"]]
+        for L in reversed(self.dec_layers):
+            buckets.append(self._layer_param_names(L, cfg["decoder_concat_after"]))
+        adaptor = []
+        if cfg["decoder_normalized_before"]:
+            buckets[0] += ["decoder.after_norm.weight", "decoder.after_norm.bias"]
+        if self.scaled:
+            adaptor.append("decoder.embed.0.alpha")
+        adaptor += [va + "pitch_embed.conv.conv.weight", va + "pitch_embed.conv.conv.bias",
+                    va + "energy_embed.conv.conv.weight", va + "energy_embed.conv.conv.bias"]
+        adaptor += self._pred_param_names(self.pitch_pred) + self._pred_param_names(self.energy_pred)
+        adaptor += self._pred_param_names(self.dur_pred)
+        if cfg["encoder_normalized_before"]:
+            adaptor += ["encoder.after_norm.weight", "encoder.after_norm.bias"]
+        buckets.append(adaptor)
+        for L in reversed(self.enc_layers):
+            buckets.append(self._layer_param_names(L, cfg["encoder_concat_after"]))
+        last = ["encoder.embed.0.weight"]
+        if self.scaled:
+            last.append("encoder.embed.1.alpha")
+        buckets.append(last)
+        names = [n for b in buckets for n in b]
+        assert sorted(names) == sorted(self.P), (sorted(set(self.P) - set(names)), sorted(set(names) - set(self.P)))
+        off, self.G, self.bucket_slices = 0, {}, []
+        offsets = {}
+        for b in buckets:
+            start = off
+            for n in b:
+                off = -(-off // 4) * 4               # 16-byte alignment of every gradient
+                offsets[n] = off
+                off += self.P[n].numel()
+            self.bucket_slices.append((start, off))
+        self.flat = torch.zeros((off,), device=self.dev)
+        for n, o in offsets.items():
+            self.G[n] = self.flat[o:o + self.P[n].numel()].view(self.P[n].shape)
+
+    # ------------------------------------------------------------------ helpers
+    def _pe_table(self, T):
+        if self._pe is None or self._pe.shape[0] < T:
+            n = 1 << (max(T, 1024) - 1).bit_length()
+            self._pe = posenc_table(n, self.d).to(self.dev)
+        return self._pe
+
+    def _empty(self, shape, dtype=None):
+        return torch.empty(shape, device=self.dev, dtype=dtype or self.tdt)
+
+    def _ws(self, nbytes):
+        return torch.empty((max(int(nbytes), 16) + 3) // 4, device=self.dev, dtype=torch.float32)
+
+    def _ksplit(self, M, N, Cin, taps):
+        nch = -(-Cin // (64 if self.code == BF16 else 32))
+        blocks = -(-M // 128) * -(-N // 128)
+        if blocks >= 200 or nch * taps < 32:
+            return 1
+        ks = max(1, min(nch, 8, 256 // blocks))
+        while ks > 1 and (nch // ks) * taps < 8:
+            ks -= 1
+        return ks
+
+    def _gemm(self, x, w, bias, M, N, Cin, taps, seg=None, res=None, relu=0, out_f32=False, ksplit=1, out=None,
+              ldx=None, gate=None, tag=None):
+        if out is None:
+            shape = (ksplit, M, N) if ksplit > 1 else (M, N)
+            out = self._empty(shape, dtype=torch.float32 if out_f32 else self.tdt)
+        ldx = Cin if ldx is None else ldx
+        t0 = self._tic(tag)
+        if gate is not None:
+            call("fs2_conv_gemm_gated", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(gate), ptr(out), ptr(seg), M, N, Cin,
+                 taps, ldx, N, N, N, int(out_f32), self.code, stream())
+        else:
+            call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps, ldx, N, N,
+                 int(relu), int(out_f32), self.code, ksplit, M * N, stream())
+        self._toc(tag, t0, 2.0 * M * N * Cin * taps)
+        return out
+
+    def _tic(self, tag):
+        if self.profile is None or tag is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _toc(self, tag, e0, flops):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.profile.append((tag, flops, e0, e1))
+
+    def _ln(self, x, w, b, M, C, want_f32, want_t, parts=None, sum_out=None):
+        of = self._empty((M, C), torch.float32) if (want_f32 or (want_t and self.code == F32)) else None
+        ot = self._empty((M, C)) if (want_t and self.code != F32) else None
+        nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
+        call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
+             M, C, LN_EPS, self.code, stream())
+        return of, (of if self.code == F32 else ot)
+
+    def _ln_bwd(self, x, dy, parts, w, dres, M, C, dw=None, db=None, relu_gate=False, want_f32=True, want_t=True):
+        """returns (dx fp32 or None, dx as T or None)"""
+        f32 = self.code == F32
+        of = self._empty((M, C), torch.float32) if (want_f32 or (want_t and f32)) else None
+        ot = self._empty((M, C)) if (want_t and not f32) else None
+        nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
+        ws = self._ws(hip.load().fs2_layernorm_bwd_workspace(M, C)) if w is not None else None
+        call("fs2_layernorm_bwd", ptr(x), ptr(dy), ptr(parts), nparts, M * C, ptr(w), ptr(dres), int(relu_gate), ptr(of),
+             ptr(ot), ptr(dw), ptr(db), ptr(ws), M, C, LN_EPS, 0, self.code, stream())
+        return of, (of if f32 else ot)
+
+    def _wgrad_split(self, M, N, Cin, taps):
+        bch = 64 if self.code == F32 else 128
+        tiles = -(-N // bch) * -(-Cin // bch) * taps
+        nblocks = max(1, -(-M // 64))
+        ks = max(1, min(64, nblocks, -(-1024 // tiles)))
+        return ks
+
+    def _wgrad(self, dy, x, grad, seg, M, N, Cin, taps, ldy=None, ldx=None, tag="wgrad"):
+        ks = self._wgrad_split(M, N, Cin, taps)
+        ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
+        t0 = self._tic(tag)
+        call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(ws), ptr(seg) if taps > 1 else None, M, N, Cin, taps,
+             N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
+        self._toc(tag, t0, 2.0 * M * N * Cin * taps)
+
+    def _colsum(self, G, out, M, C, ldg=None, g_is_t=True, S=None, R=1, scale=1.0, pe=None, pos=None):
+        ws = self._ws(hip.load().fs2_colreduce_workspace(M, C, R))
+        gd = 1 if (g_is_t and self.code == BF16) else 0
+        call("fs2_colreduce", ptr(G), gd, C if ldg is None else ldg, ptr(S), 0 if S is None else S.shape[1], R, ptr(pe),
+             ptr(pos), ptr(out), ptr(ws), M, C, float(scale), 0, stream())
+
+    def refresh_weights(self):
+        """Re-pack every GEMM operand from the current parameter values (call once per step)."""
+        for L, ca in [(l, self.cfg["encoder_concat_after"]) for l in self.enc_layers] + \
+                     [(l, self.cfg["decoder_concat_after"]) for l in self.dec_layers]:
+            p = L["prefix"]
+            torch.cat([self.P[p + "self_atten.linear_%s.bias" % n].data for n in "qkv"], 0, out=L["bqkv"])
+            if ca:
+                wc = self.P[p + "concat_linear.weight"].data
+                L["wc_x"].params[0].data.copy_(wc[:, :self.d])
+                L["wc_a"].params[0].data.copy_(wc[:, self.d:])
+        for w in self._all_weights():
+            w.pack(self.code)
+
+    # ------------------------------------------------------------------ forward pieces
+    def _stack_fwd(self, layers, prefix, pre_ln, concat_after, x32, xt, seg, cu, B, max_len, M):
+        d, P = self.d, self.P
+        recs, pend = [], None
+        for L in layers:
+            p = L["prefix"]
+            r = {}
+            if pre_ln:
+                xs = x32 if pend is None else self._empty((M, d), torch.float32)
+                a_t = self._ln(x32, P[p + "norm1.weight"], P[p + "norm1.bias"], M, d, False, True, parts=pend,
+                               sum_out=xs if pend is not None else None)[1]
+                x32 = xs
+                r["x_ln1"] = x32
+            else:
+                a_t = xt
+            r["a_t"] = a_t
+            qkv = self._gemm(a_t, L["wqkv"].fwd, L["bqkv"], M, 3 * d, d, 1)
+            ctx = self._empty((M, d))
+            lse = self._empty((self.h, M), torch.float32)
+            call("fs2_attention_fwd", ptr(qkv), ptr(ctx), ptr(lse), ptr(cu), B, max_len, M, self.h, self.dk, 3 * d, d,
+                 self.code, stream())
+            r.update(qkv=qkv, ctx=ctx, lse=lse)
+            if concat_after:
+                att = self._gemm(ctx, L["wo"].fwd, P[p + "self_atten.linear_out.bias"], M, d, d, 1)
+                pend = self._empty((2, M, d), torch.float32)
+                self._gemm(a_t, L["wc_x"].fwd, P[p + "concat_linear.bias"], M, d, d, 1, out_f32=True, out=pend[0])
+                self._gemm(att, L["wc_a"].fwd, None, M, d, d, 1, out_f32=True, out=pend[1])
+                r["att"] = att
+            else:
+                pend = self._gemm(ctx, L["wo"].fwd, P[p + "self_atten.linear_out.bias"], M, d, d, 1, out_f32=True,
+                                  ksplit=self._ksplit(M, d, d, 1))
+            if pre_ln:
+                x1 = self._empty((M, d), torch.float32)
+                f_t = self._ln(x32, P[p + "norm2.weight"], P[p + "norm2.bias"], M, d, False, True, parts=pend,
+                               sum_out=x1)[1]
+                x32 = x1
+                r["x_ln2"] = x1
+            else:
+                s1 = self._empty((M, d), torch.float32)
+                x32, xt = self._ln(x32, P[p + "norm1.weight"], P[p + "norm1.bias"], M, d, True, True, parts=pend,
+                                   sum_out=s1)
+                r["s1"] = s1
+                f_t = xt
+            r["f_t"] = f_t
+            w1, w2 = L["w1"], L["w2"]
+            sg = seg if w1.k > 1 else None
+            hdn = self._gemm(f_t, w1.fwd, P[p + "feed_forward.w1.bias"], M, w1.N, d, w1.k, seg=sg, relu=1, tag="ffn1")
+            pend = self._gemm(hdn, w2.fwd, P[p + "feed_forward.w2.bias"], M, d, w1.N, w2.k, seg=sg, out_f32=True,
+                              ksplit=self._ksplit(M, d, w1.N, w2.k), tag="ffn2")
+            r["hdn"] = hdn
+            if not pre_ln:
+                s2 = self._empty((M, d), torch.float32)
+                x32, xt = self._ln(x32, P[p + "norm2.weight"], P[p + "norm2.bias"], M, d, True, True, parts=pend,
+                                   sum_out=s2)
+                r["s2"] = s2
+                pend = None
+            recs.append(r)
+        after = None
+        if pre_ln:
+            after = self._empty((M, d), torch.float32)
+            x32, xt = self._ln(x32, P[prefix + "after_norm.weight"], P[prefix + "after_norm.bias"], M, d, True, True,
+                               parts=pend, sum_out=after)
+        return x32, xt, dict(layers=recs, after=after)
+
+    def _stack_bwd(self, layers, prefix, pre_ln, concat_after, saved, dy, dparts, seg, cu, B, max_len, M, first_ready):
+        """dy (+ dparts): gradient wrt the stack output.  Returns the gradient wrt the stack input as (dy, parts).
+        first_ready: gradient bucket that is complete once the stack's after_norm has been processed."""
+        d, P, G = self.d, self.P, self.G
+        if pre_ln:
+            dy, dyt = self._ln_bwd(saved["after"], dy, dparts, P[prefix + "after_norm.weight"], None, M, d,
+                                   dw=G[prefix + "after_norm.weight"], db=G[prefix + "after_norm.bias"])
+            dparts = None
+        if self.grad_ready is not None:
+            self.grad_ready(first_ready)
+        for L, r in zip(reversed(layers), reversed(saved["layers"])):
+            p = L["prefix"]
+            w1, w2 = L["w1"], L["w2"]
+            U = w1.N
+            sg = seg if w1.k > 1 else None
+            if not pre_ln:       # x2 = LN2(s2)
+                dy, dyt = self._ln_bwd(r["s2"], dy, dparts, P[p + "norm2.weight"], None, M, d,
+                                       dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"])
+                dparts = None
+            # ---- feed-forward: s2 = x1 + w2(relu(w1(f)))       (dy = d s2, dyt its T copy)
+            self._wgrad(dyt, r["hdn"], G[p + "feed_forward.w2.weight"], sg, M, d, U, w2.k, tag="wgrad_ffn2")
+            self._colsum(dyt, G[p + "feed_forward.w2.bias"], M, d)
+            dh = self._gemm(dyt, w2.bwd, None, M, U, d, w2.k, seg=sg, gate=r["hdn"], tag="dgrad_ffn2")
+            self._wgrad(dh, r["f_t"], G[p + "feed_forward.w1.weight"], sg, M, U, d, w1.k, tag="wgrad_ffn1")
+            self._colsum(dh, G[p + "feed_forward.w1.bias"], M, U)
+            df = self._gemm(dh, w1.bwd, None, M, d, U, w1.k, seg=sg, out_f32=True, ksplit=self._ksplit(M, d, U, w1.k),
+                            tag="dgrad_ffn1")
+            if pre_ln:           # f = LN2(x1): d x1 = dy + LN2'(df)
+                dy, dyt = self._ln_bwd(r["x_ln2"], None, df, P[p + "norm2.weight"], dy, M, d,
+                                       dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"])
+            else:                # f = x1 = LN1(s1): d s1 = LN1'(dy + df)
+                dy, dyt = self._ln_bwd(r["s1"], dy, df, P[p + "norm1.weight"], None, M, d,
+                                       dw=G[p + "norm1.weight"], db=G[p + "norm1.bias"])
+            # ---- attention: s1 = x + out(ctx)  [or x + concat_linear(cat(a, out(ctx)))]
+            da_extra = None
+            if concat_after:
+                gc = G[p + "concat_linear.weight"]
+                tmp = self._empty((d, d), torch.float32)
+                self._wgrad(dyt, r["a_t"], tmp, None, M, d, d, 1)
+                gc[:, :d].copy_(tmp)
+                self._wgrad(dyt, r["att"], tmp, None, M, d, d, 1)
+                gc[:, d:].copy_(tmp)
+                self._colsum(dyt, G[p + "concat_linear.bias"], M, d)
+                da_extra = self._gemm(dyt, L["wc_x"].bwd, None, M, d, d, 1, out_f32=True)
+                datt = self._gemm(dyt, L["wc_a"].bwd, None, M, d, d, 1)
+            else:
+                datt = dyt
+            self._wgrad(datt, r["ctx"], G[p + "self_atten.linear_out.weight"], None, M, d, d, 1)
+            self._colsum(datt, G[p + "self_atten.linear_out.bias"], M, d)
+            dctx = self._gemm(datt, L["wo"].bwd, None, M, d, d, 1)
+            dqkv = self._empty((M, 3 * d))
+            delta = self._empty((self.h, M), torch.float32)
+            call("fs2_attention_bwd", ptr(r["qkv"]), ptr(r["ctx"]), ptr(dctx), ptr(r["lse"]), ptr(delta), ptr(dqkv),
+                 ptr(cu), B, max_len, M, self.h, self.dk, 3 * d, d, self.code, stream())
+            gq = G[p + "self_atten.linear_q.weight"]
+            gqkv = self.flat[gq.storage_offset():gq.storage_offset() + 3 * d * d].view(3 * d, d)
+            self._wgrad(dqkv, r["a_t"], gqkv, None, M, 3 * d, d, 1)
+            gb = G[p + "self_atten.linear_q.bias"]
+            self._colsum(dqkv, self.flat[gb.storage_offset():gb.storage_offset() + 3 * d], M, 3 * d)
+            da = self._gemm(dqkv, L["wqkv"].bwd, None, M, d, 3 * d, 1, out_f32=True, ksplit=self._ksplit(M, d, 3 * d, 1))
+            if da_extra is not None:
+                da = torch.stack([da, da_extra], 0) if da.dim() == 2 else torch.cat([da, da_extra.unsqueeze(0)], 0)
+            if pre_ln:           # a = LN1(x): d x = dy + LN1'(da)
+                dy, dyt = self._ln_bwd(r["x_ln1"], None, da, P[p + "norm1.weight"], dy, M, d,
+                                       dw=G[p + "norm1.weight"], db=G[p + "norm1.bias"])
+                dparts = None
+            else:                # a = x: d x = dy + da, folded into the next LayerNorm backward
+                dparts = da
+            if self.grad_ready is not None:
+                self.grad_ready(self._bucket_of[p])
+        return dy, dparts
+
+    def _pred_fwd(self, pr, x_t, seg, M, cin):
+        P = self.P
+        cur, recs = x_t, []
+        n = len(pr["convs"])
+        y32 = None
+        for j, c in enumerate(pr["convs"]):
+            w = c["w"]
+            y = self._gemm(cur, w.fwd, P[c["p"] + "0.conv.bias"], M, w.N, cin, w.k, seg=seg if w.k > 1 else None, relu=1,
+                           out_f32=True)
+            recs.append(dict(inp=cur, y=y))
+            last = j == n - 1
+            y32, cur = self._ln(y, P[c["p"] + "2.weight"], P[c["p"] + "2.bias"], M, w.N, last, not last)
+            cin = w.N
+        out = self._empty((M, pr["nout"]), torch.float32)
+        call("fs2_rowdot", ptr(y32), ptr(P[pr["prefix"] + "linear.weight"]), ptr(P[pr["prefix"] + "linear.bias"]),
+             ptr(out), M, cin, pr["nout"], stream())
+        return out, dict(convs=recs, y32=y32)
+
+    def _pred_bwd(self, pr, saved, dout, seg, M, cin0, acc):
+        """dout fp32 [M, nout]; adds the gradient wrt the predictor input into `acc` (fp32 [M, cin0])."""
+        P, G = self.P, self.G
+        pre = pr["prefix"]
+        nout = pr["nout"]
+        C = pr["convs"][-1]["w"].N
+        self._colsum(saved["y32"], G[pre + "linear.weight"], M, C, g_is_t=False, S=dout, R=nout)
+        self._colsum(dout, G[pre + "linear.bias"], M, nout, g_is_t=False)
+        dcur = self._empty((M, C), torch.float32)
+        call("fs2_rowdot_bwd", ptr(dout), ptr(P[pre + "linear.weight"]), ptr(dcur), M, C, nout, stream())
+        dparts = None
+        for j in range(len(pr["convs"]) - 1, -1, -1):
+            c, r = pr["convs"][j], saved["convs"][j]
+            w = c["w"]
+            cin = cin0 if j == 0 else pr["convs"][j - 1]["w"].N
+            sg = seg if w.k > 1 else None
+            _, dpre = self._ln_bwd(r["y"], dcur, dparts, P[c["p"] + "2.weight"], None, M, w.N, dw=G[c["p"] + "2.weight"],
+                                   db=G[c["p"] + "2.bias"], relu_gate=True, want_f32=False)
+            self._wgrad(dpre, r["inp"], G[c["p"] + "0.conv.weight"], sg, M, w.N, cin, w.k)
+            self._colsum(dpre, G[c["p"] + "0.conv.bias"], M, w.N)
+            if j == 0:
+                self._gemm(dpre, w.bwd, None, M, cin, w.N, w.k, seg=sg, res=acc, out_f32=True, out=acc)
+            else:
+                dcur = None
+                dparts = self._gemm(dpre, w.bwd, None, M, cin, w.N, w.k, seg=sg, out_f32=True,
+                                    ksplit=self._ksplit(M, cin, w.N, w.k))
+
+    # ------------------------------------------------------------------ one step
+    def forward(self, ids, ilens, olens, ds, ps, es, ys):
+        """ids int64 [Mp], ds int32 [Mp], ps fp32 [Mf,4], es fp32 [Mf,1], ys fp32 [Mf,odim] — packed, on the device.
+        Returns (loss terms as device scalars, saved state for `backward`)."""
+        dev, d, P, cfg = self.dev, self.d, self.P, self.cfg
+        self.refresh_weights()
+        B = len(ilens)
+        ilens = [int(v) for v in ilens]
+        Mp = int(sum(ilens))
+        cu_p = np.zeros(B + 1, np.int32)
+        cu_p[1:] = np.cumsum(ilens)
+        cu_phone = torch.from_numpy(cu_p).to(dev, non_blocking=True)
+        max_il = max(ilens)
+        seg_p = self._empty((Mp, 2), torch.int32)
+        pos_p = self._empty((Mp,), torch.int32)
+        call("fs2_build_seg", ptr(cu_phone), B, ptr(seg_p), ptr(pos_p), Mp, stream())
+        pe = self._pe_table(max_il)
+        if self.scaled:
+            a_enc, a_dec = P["encoder.embed.1.alpha"], P["decoder.embed.0.alpha"]
+            enc_alpha, dec_alpha = float(a_enc), float(a_dec)      # host read of two scalars (once per step)
+            xscale = 1.0
+        else:
+            enc_alpha = dec_alpha = 1.0
+            xscale = math.sqrt(d)
+        enc_pre, dec_pre = cfg["encoder_normalized_before"], cfg["decoder_normalized_before"]
+        x32 = self._empty((Mp, d), torch.float32)
+        xt = self._empty((Mp, d)) if (not enc_pre and self.code != F32) else None
+        call("fs2_embed_posenc", ptr(ids), ptr(pos_p), ptr(P["encoder.embed.0.weight"]), ptr(pe), xscale, enc_alpha,
+             ptr(x32), ptr(xt), Mp, d, self.idim, self.code, stream())
+        if self.code == F32:
+            xt = x32
+        hs32, hst, enc_saved = self._stack_fwd(self.enc_layers, "encoder.", enc_pre, cfg["encoder_concat_after"], x32, xt,
+                                               seg_p, cu_phone, B, max_il, Mp)
+        logd, dur_saved = self._pred_fwd(self.dur_pred, hst, seg_p, Mp, d)
+        # LengthRegulator with the ground-truth durations (network/variance_adaptor.py:187)
+        dur_used = self._empty((Mp,), torch.int32)
+        cum = self._empty((Mp,), torch.int32)
+        olens_dev = self._empty((B,), torch.int32)
+        cu_frames = self._empty((B + 1,), torch.int32)
+        call("fs2_lr_plan", ptr(ds), ptr(cu_phone), 1.0, ptr(dur_used), ptr(cum), ptr(olens_dev), ptr(cu_frames), B,
+             stream())
+        Mf = int(ys.shape[0])      # the caller guarantees sum(ds) == olens per utterance (no device read needed)
+        olens = [int(v) for v in olens]
+        assert sum(olens) == Mf
+        max_ol = max(olens)
+        hs_lr32 = self._empty((Mf, d), torch.float32)
+        hs_lrt = self._empty((Mf, d)) if self.code != F32 else None
+        seg_f = self._empty((Mf, 2), torch.int32)
+        pos_f = self._empty((Mf,), torch.int32)
+        lr_index = self._empty((Mf,), torch.int32)
+        call("fs2_lr_gather", ptr(hs32), ptr(cum), ptr(cu_phone), ptr(cu_frames), B, ptr(hs_lr32), ptr(hs_lrt),
+             ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, self.code, stream())
+        if self.code == F32:
+            hs_lrt = hs_lr32
+        pitch, pitch_saved = self._pred_fwd(self.pitch_pred, hs_lrt, seg_f, Mf, d)
+        energy, energy_saved = self._pred_fwd(self.energy_pred, hs_lrt, seg_f, Mf, d)
+        va = "variance_adaptor."
+        pe_f = self._pe_table(max_ol)
+        y32 = self._empty((Mf, d), torch.float32)
+        yt = self._empty((Mf, d)) if (not dec_pre and self.code != F32) else None
+        call("fs2_variance_add_posenc", ptr(hs_lr32), ptr(ps), ptr(es), ptr(P[va + "pitch_embed.conv.conv.weight"]),
+             ptr(P[va + "pitch_embed.conv.conv.bias"]), ptr(P[va + "energy_embed.conv.conv.weight"]),
+             ptr(P[va + "energy_embed.conv.conv.bias"]), 1.0, 1.0, ptr(pe_f), ptr(pos_f), xscale, dec_alpha, None,
+             ptr(y32), ptr(yt), Mf, d, self.pdim, self.edim, self.code, stream())
+        if self.code == F32:
+            yt = y32
+        z32, zt, dec_saved = self._stack_fwd(self.dec_layers, "decoder.", dec_pre, cfg["decoder_concat_after"], y32, yt,
+                                             seg_f, cu_frames, B, max_ol, Mf)
+        before = self._gemm(zt, self.w_out.fwd, P["feat_out.bias"], Mf, self.odim, d, 1, out_f32=True)
+        saved = dict(B=B, Mp=Mp, Mf=Mf, max_il=max_il, max_ol=max_ol, ids=ids, ds=ds, ps=ps, es=es, ys=ys,
+                     cu_phone=cu_phone, cu_frames=cu_frames, seg_p=seg_p, seg_f=seg_f, pos_p=pos_p, pos_f=pos_f,
+                     dur_used=dur_used, cum=cum, enc=enc_saved, dec=dec_saved, dur=dur_saved, pitch=pitch_saved,
+                     energy=energy_saved, hst=hst, hs_lrt=hs_lrt, zt=zt, before=before, logd=logd, pitch_out=pitch,
+                     energy_out=energy, xscale=xscale, keep=(olens_dev, lr_index, hs_lr32, x32, y32, z32))
+        return dict(before=before, log_durations=logd.view(-1), pitch=pitch, energy=energy), saved
+
+    def backward(self, s, upstream: Optional[torch.Tensor] = None):
+        """Fills self.G (all parameter gradients, fp32) for loss = L1(before, ys) + MSE(logd, log(ds+1)) +
+        MSE(pitch, ps) + MSE(energy, es), each a mean over the packed elements, times `upstream` (device scalar)."""
+        d, P, G, cfg = self.d, self.P, self.G, self.cfg
+        B, Mp, Mf = s["B"], s["Mp"], s["Mf"]
+        va = "variance_adaptor."
+        up = ptr(upstream) if upstream is not None else None
+        self._bucket_of = {}
+        bi = 1
+        for L in reversed(self.dec_layers):
+            self._bucket_of[L["prefix"]] = bi
+            bi += 1
+        adaptor_bucket = bi
+        bi += 1
+        for L in reversed(self.enc_layers):
+            self._bucket_of[L["prefix"]] = bi
+            bi += 1
+        # ---- mel loss -> feat_out
+        dbt = self._empty((Mf, self.odim_pad))
+        call("fs2_loss_grad", ptr(s["before"]), ptr(s["ys"]), None, 0, 1.0 / (Mf * self.odim), up, None, ptr(dbt), Mf,
+             self.odim, self.odim_pad, self.code, stream())
+        self._wgrad(dbt, s["zt"], G["feat_out.weight"], None, Mf, self.odim, d, 1, ldy=self.odim_pad)
+        self._colsum(dbt, G["feat_out.bias"], Mf, self.odim, ldg=self.odim_pad)
+        dz = self._gemm(dbt, self.w_out.bwd, None, Mf, d, self.odim_pad, 1, out_f32=True)
+        # ---- decoder stack
+        dy, dparts = self._stack_bwd(self.dec_layers, "decoder.", cfg["decoder_normalized_before"],
+                                     cfg["decoder_concat_after"], s["dec"], dz, None, s["seg_f"], s["cu_frames"], B,
+                                     s["max_ol"], Mf, 0)
+        if dparts is not None:      # materialise the sum
+            dy, _ = self._ln_bwd(None, dy, dparts, None, None, Mf, d, want_t=False)
+        # ---- decoder positional encoding + variance embeddings (y = xscale * (hs_lr + emb) + alpha pe)
+        if self.scaled:
+            tmp = self._empty((d,), torch.float32)
+            self._colsum(dy, tmp, Mf, d, g_is_t=False, pe=self._pe_table(s["max_ol"]), pos=s["pos_f"])
+            torch.sum(tmp, 0, out=G["decoder.embed.0.alpha"])
+        S = torch.cat([s["ps"], s["es"], torch.ones((Mf, 1), device=self.dev)], 1).contiguous()
+        R = self.pdim + self.edim + 1
+        emb = self._empty((R, d), torch.float32)
+        self._colsum(dy, emb, Mf, d, g_is_t=False, S=S, R=R, scale=s["xscale"])
+        G[va + "pitch_embed.conv.conv.weight"].copy_(emb[:self.pdim].t().unsqueeze(-1))
+        G[va + "energy_embed.conv.conv.weight"].copy_(emb[self.pdim:self.pdim + self.edim].t().unsqueeze(-1))
+        G[va + "pitch_embed.conv.conv.bias"].copy_(emb[R - 1])
+        G[va + "energy_embed.conv.conv.bias"].copy_(emb[R - 1])
+        if s["xscale"] != 1.0:
+            acc = self._empty((Mf, d), torch.float32)
+            call("fs2_scale", ptr(dy), float(s["xscale"]), ptr(acc), Mf * d, stream())
+        else:
+            acc = dy
+        # ---- pitch / energy predictors (inputs: hs_lr before the embedding add)
+        for pr, saved, out, tgt in ((self.pitch_pred, s["pitch"], s["pitch_out"], s["ps"]),
+                                    (self.energy_pred, s["energy"], s["energy_out"], s["es"])):
+            n = pr["nout"]
+            dout = self._empty((Mf, n), torch.float32)
+            call("fs2_loss_grad", ptr(out), ptr(tgt), None, 1, 1.0 / (Mf * n), up, ptr(dout), None, Mf, n, n, self.code,
+                 stream())
+            self._pred_bwd(pr, saved, dout, s["seg_f"], Mf, d, acc)
+        # ---- LengthRegulator backward, duration predictor
+        dhs = self._empty((Mp, d), torch.float32)
+        call("fs2_lr_scatter", ptr(acc), ptr(s["dur_used"]), ptr(s["cum"]), ptr(s["cu_phone"]), ptr(s["cu_frames"]), B,
+             None, 1.0, ptr(dhs), Mp, d, stream())
+        dlog = self._empty((Mp, 1), torch.float32)
+        call("fs2_loss_grad", ptr(s["logd"]), None, ptr(s["ds"]), 2, 1.0 / Mp, up, ptr(dlog), None, Mp, 1, 1, self.code,
+             stream())
+        self._pred_bwd(self.dur_pred, s["dur"], dlog, s["seg_p"], Mp, d, dhs)
+        # ---- encoder stack
+        dx, dparts = self._stack_bwd(self.enc_layers, "encoder.", cfg["encoder_normalized_before"],
+                                     cfg["encoder_concat_after"], s["enc"], dhs, None, s["seg_p"], s["cu_phone"], B,
+                                     s["max_il"], Mp, adaptor_bucket)
+        if dparts is not None:
+            dx, _ = self._ln_bwd(None, dx, dparts, None, None, Mp, d, want_t=False)
+        call("fs2_embed_bwd", ptr(s["ids"]), ptr(dx), float(s["xscale"]), ptr(G["encoder.embed.0.weight"]), Mp, d,
+             self.idim, 0, stream())
+        if self.scaled:
+            tmp = self._empty((d,), torch.float32)
+            self._colsum(dx, tmp, Mp, d, g_is_t=False, pe=self._pe_table(s["max_il"]), pos=s["pos_p"])
+            torch.sum(tmp, 0, out=G["encoder.embed.1.alpha"])
+        if self.grad_ready is not None:
+            self.grad_ready(len(self.bucket_slices) - 1)
+        return G

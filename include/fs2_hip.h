@@ -193,10 +193,11 @@ int fs2_embed_bwd(const long long* ids, const float* dx, float xscale, float* de
                   int accumulate, hipStream_t stream);
 
 /* Loss gradients (network/fastspeech2.py:259-279, network/loss.py:5-14): mode 0 L1, 1 MSE, 2 MSE against
- * log(dur + 1); scale = upstream gradient / element count.  Writes fp32 [M, C] and/or T [M, ldt]
+ * log(dur + 1); scale = 1 / element count, times *scale_dev (the upstream gradient as a device
+ * scalar, may be NULL) so that no host read is needed.  Writes fp32 [M, C] and/or T [M, ldt]
  * (pad columns zero-filled so the matrix can feed the MFMA kernels). */
-int fs2_loss_grad(const float* pred, const float* tgt, const int* dur, int mode, float scale, float* g_f32, void* g_t,
-                  int M, int C, int ldt, int dtype, hipStream_t stream);
+int fs2_loss_grad(const float* pred, const float* tgt, const int* dur, int mode, float scale, const float* scale_dev,
+                  float* g_f32, void* g_t, int M, int C, int ldt, int dtype, hipStream_t stream);
 
 /* out = a * x (fp32). */
 int fs2_scale(const float* x, float a, float* out, long long n, hipStream_t stream);

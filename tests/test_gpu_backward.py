@@ -215,17 +215,18 @@ def test_lr_scatter_embed_bwd_loss_grad():
     pred, tgt = torch.randn(M, 20, generator=g), torch.randn(M, 20, generator=g)
     pd_, td_ = pred.to(DEV), tgt.to(DEV)
     g32 = torch.empty((M, 20), device=DEV)
+    two = torch.full((1,), 2.0, device=DEV)
     gt = torch.full((M, 24), 9.0, device=DEV, dtype=torch.bfloat16)
-    call("fs2_loss_grad", ptr(pd_), ptr(td_), None, 0, 0.25, ptr(g32), ptr(gt), M, 20, 24, 1, stream())
+    call("fs2_loss_grad", ptr(pd_), ptr(td_), None, 0, 0.125, ptr(two), ptr(g32), ptr(gt), M, 20, 24, 1, stream())
     assert torch.equal(g32.cpu(), 0.25 * torch.sign(pred - tgt))
     assert torch.equal(gt.float().cpu()[:, :20], 0.25 * torch.sign(pred - tgt)) and (gt[:, 20:] == 0).all()
-    call("fs2_loss_grad", ptr(pd_), ptr(td_), None, 1, 0.25, ptr(g32), None, M, 20, 20, 0, stream())
+    call("fs2_loss_grad", ptr(pd_), ptr(td_), None, 1, 0.25, None, ptr(g32), None, M, 20, 20, 0, stream())
     assert (g32.cpu() - 0.5 * (pred - tgt)).abs().max().item() <= 1e-6
     durd = torch.randint(0, 9, (M, 1), generator=g, dtype=torch.int32)
     logd = torch.randn(M, 1, generator=g)
     ld_, dd_ = logd.to(DEV), durd.to(DEV)
     gd = torch.empty((M, 1), device=DEV)
-    call("fs2_loss_grad", ptr(ld_), None, ptr(dd_), 2, 0.5, ptr(gd), None, M, 1, 1, 0, stream())
+    call("fs2_loss_grad", ptr(ld_), None, ptr(dd_), 2, 0.5, None, ptr(gd), None, M, 1, 1, 0, stream())
     assert (gd.cpu() - (logd - torch.log(durd.float() + 1.0))).abs().max().item() <= 1e-6
 
 
