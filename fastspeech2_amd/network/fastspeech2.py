@@ -328,34 +328,43 @@ class FeedForwardTransformer(nn.Module):
             self._train_engine_key = key
         return self._train_engine
 
-    def _forward_train(self, xs, ilens, ys, olens, ds, ps, es):
+    def pack_batch(self, xs, ilens, ys, olens, ds, ps, es):
+        """Padded training batch (the converter's tensors, run/train_decode.py:126-149) -> packed device
+        tensors, validated once (sum(ds) == olens per utterance).  The result can be fed to `forward` as
+        `packed=` on every step of a loop that re-uses the batch, skipping the re-packing."""
+        eng = self.train_engine()
+        il, ol = [int(v) for v in ilens], [int(v) for v in olens]
+        dev = eng.dev
+        ids = self._pack(xs[:, :max(il)].to(dev), il).to(torch.int64).contiguous()
+        ds_p = self._pack(ds[:, :max(il)].to(dev), il).to(torch.int32).contiguous()
+        if [int(v) for v in self._segment_sums(ds_p, il)] != ol:
+            raise ValueError("sum(ds) per utterance must equal olens")
+        ys_p = self._pack(ys[:, :max(ol)].to(dev), ol).float().contiguous()
+        ps_p = self._pack(ps[:, :max(ol)].to(dev), ol).float().contiguous()
+        es_p = self._pack(es[:, :max(ol)].to(dev), ol).float().contiguous()
+        return (ids, il, ol, ds_p, ps_p, es_p, ys_p)
+
+    def _forward_train(self, packed):
         """Teacher-forced step with a backward: the loss tensor is the output of one autograd node whose
         backward runs the HIP backward schedule and hands every parameter its gradient, so the reference's
         `loss.backward(); clip_grad_norm_; optimizer.step()` (run/train_decode.py:94-110) works unchanged."""
         eng = self.train_engine()
-        il, ol = [int(v) for v in ilens], [int(v) for v in olens]
-        dev = eng.dev
-        ids = self._pack(xs.to(dev), il).to(torch.int64).contiguous()
-        ds_p = self._pack(ds.to(dev), il).to(torch.int32).contiguous()
-        if [int(v) for v in self._segment_sums(ds_p, il)] != ol:
-            raise ValueError("sum(ds) per utterance must equal olens")
-        ys_p = self._pack(ys.to(dev), ol).float().contiguous()
-        ps_p = self._pack(ps.to(dev), ol).float().contiguous()
-        es_p = self._pack(es.to(dev), ol).float().contiguous()
         names = list(eng.P)
-        return _TrainStep.apply(self, eng, (ids, il, ol, ds_p, ps_p, es_p, ys_p), names, *[eng.P[n] for n in names])
+        return _TrainStep.apply(self, eng, packed, names, *[eng.P[n] for n in names])
 
-    def forward(self, xs, ilens, ys, olens, ds, ps, es, **_ignored):
+    def forward(self, xs=None, ilens=None, ys=None, olens=None, ds=None, ps=None, es=None, packed=None, **_ignored):
         """Loss of one teacher-forced step (network/fastspeech2.py:232-295).  Extra keys produced by
         the reference's converter (`labels`, `spkids`, run/train_decode.py:136-149) are ignored.
         In training mode with grad enabled the returned loss carries a backward (HIP kernels, see
         `_forward_train`); under `torch.no_grad()` / `eval()` it is the plain value (evaluator path,
         run/train_decode.py:42-57).  Dropout is never applied."""
+        if self.training and torch.is_grad_enabled() and self.postnet is None:
+            return self._forward_train(packed if packed is not None else self.pack_batch(xs, ilens, ys, olens, ds, ps, es))
+        if xs is None:
+            raise ValueError("`packed=` batches are for the training path (train mode, grad enabled)")
         il, ol = [int(v) for v in ilens], [int(v) for v in olens]
         xs, ds = xs[:, :max(il)], ds[:, :max(il)]
         ys, ps, es = ys[:, :max(ol)], ps[:, :max(ol)], es[:, :max(ol)]
-        if self.training and torch.is_grad_enabled() and self.postnet is None:
-            return self._forward_train(xs, ilens, ys, olens, ds, ps, es)
         _, _, out = self._forward(xs, ilens, olens, ds, ps, es, is_inference=False, _raw=True)
         dev = out["mel"].device
         if not self.use_masking:

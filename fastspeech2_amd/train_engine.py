@@ -82,6 +82,7 @@ class TrainEngine:
         self._build_grad_buffer()
         self._pe = None
         self.grad_ready: Optional[Callable[[int], None]] = None   # called with the index of a finished bucket
+        self.grad_finish: Optional[Callable[[], None]] = None     # called when every bucket has been announced
         self.profile = None
 
     # ------------------------------------------------------------------ set-up
@@ -631,4 +632,6 @@ class TrainEngine:
             torch.sum(tmp, 0, out=G["encoder.embed.1.alpha"])
         if self.grad_ready is not None:
             self.grad_ready(len(self.bucket_slices) - 1)
+        if self.grad_finish is not None:
+            self.grad_finish()
         return G
