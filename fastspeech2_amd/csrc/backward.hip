@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // mode 1 (pe): S is ignored, part[blk][0][c] = sum_m G[m][c] * pe[pos[m]][c]  (d alpha of the scaled
 // positional encoding, network/encoder.py:142-145).  G is fp32 (g_is_t == 0) or T.
 // ---------------------------------------------------------------------------------------
-constexpr int CR_ROWS = 128;
+constexpr int CR_ROWS = 32;
 constexpr int CR_MAXR = 8;
 
 template <typename T>
@@ -160,15 +160,26 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const void* __restrict__
     }
 }
 
-// stage 2: out[w] = scale * sum_blk part[blk * stride + w] (+ out[w])
-__global__ void colreduce_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int W,
-                                        long long stride, float scale, int accumulate) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
+// stage 2: out[w] = scale * sum_blk part[blk * stride + w] (+ out[w]).  64 columns per workgroup, 16 row
+// groups that each sum every 16th partial, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void colreduce_finish_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                int nblk, int W, long long stride, float scale,
+                                                                int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int w = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * stride + w];
-    s *= scale;
-    out[w] = accumulate ? out[w] + s : s;
+    if (w < W)
+        for (int b = ty; b < nblk; b += 16) s += part[(size_t)b * stride + w];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && w < W) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][tx];
+        t *= scale;
+        out[w] = accumulate ? out[w] + t : t;
+    }
 }
 
 // dx[m, c] = sum_j dy[m, j] * W[j, c] — input gradient of the predictors' final nn.Linear
@@ -222,23 +233,54 @@ __global__ __launch_bounds__(256) void lr_scatter_kernel(const float* __restrict
 }
 
 // Embedding backward: demb[v, :] = xscale * sum_{m : ids[m] == v} dx[m, :], row 0 (padding_idx) = 0.
-// One workgroup per vocabulary row; the id list is a few thousand entries.
+// One workgroup per vocabulary row: the id list is scanned 256 entries at a time, matching rows are
+// queued in LDS in index order (deterministic sum), then all threads add those rows.
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dx,
                                                         float xscale, float* __restrict__ demb, int M, int d, int idim,
                                                         int accumulate) {
+    __shared__ int rows[256];
+    __shared__ int wcount[4];
     const int v = blockIdx.x;
-    for (int c = threadIdx.x; c < d; c += 256) {
-        float s = 0.f;
-        if (v != 0) {
-            for (int m = 0; m < M; ++m) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};       // channels threadIdx.x + 256 j  (d <= 1024)
+    if (v != 0) {
+        for (int base = 0; base < M; base += 256) {
+            const int m = base + threadIdx.x;
+            bool hit = false;
+            if (m < M) {
                 long long id = ids[m];
                 id = id < 0 ? 0 : (id >= idim ? idim - 1 : id);
-                if (id == v) s += dx[(size_t)m * d + c];
+                hit = id == v;
             }
+            const unsigned long long bal = __ballot(hit);
+            if (lane == 0) wcount[wave] = __popcll(bal);
+            __syncthreads();
+            int off = 0, total = 0;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) off += wcount[w];
+                total += wcount[w];
+            }
+            if (hit) rows[off + __popcll(bal & ((1ull << lane) - 1ull))] = m;
+            __syncthreads();
+            for (int r = 0; r < total; ++r) {
+                const float* src = dx + (size_t)rows[r] * d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = threadIdx.x + 256 * j;
+                    if (c < d) acc[j] += src[c];
+                }
+            }
+            __syncthreads();
         }
-        s *= xscale;
-        float* dst = demb + (size_t)v * d + c;
-        *dst = accumulate ? *dst + s : s;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < d) {
+            float* dst = demb + (size_t)v * d + c;
+            const float t = acc[j] * xscale;
+            *dst = accumulate ? *dst + t : t;
+        }
     }
 }
 
@@ -336,9 +378,9 @@ extern "C" int fs2_layernorm_bwd(const float* x, const float* dy, const float* p
     FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
     if (w) {
         // part is [blocks][2][C]: gamma and beta sums finish in two strided passes
-        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 256)), dim3(256), 0, stream, part, dw, blocks, C,
+        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, stream, part, dw, blocks, C,
                            (long long)2 * C, 1.0f, accumulate);
-        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 256)), dim3(256), 0, stream, part + C, db, blocks, C,
+        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, stream, part + C, db, blocks, C,
                            (long long)2 * C, 1.0f, accumulate);
         FS2_CHECK_LAUNCH("fs2_layernorm_bwd(finish)");
     }
@@ -367,7 +409,7 @@ extern "C" int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S
         hipLaunchKernelGGL(colreduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, G, 0, ldg, S, lds, R, pe, pos,
                            workspace, M, C);
     }
-    hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk((long long)R * C, 256)), dim3(256), 0, stream, workspace, out,
+    hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk((long long)R * C, 64)), dim3(1024), 0, stream, workspace, out,
                        blocks, R * C, (long long)R * C, scale, accumulate);
     FS2_CHECK_LAUNCH("fs2_colreduce");
     return FS2_OK;
@@ -397,7 +439,7 @@ extern "C" int fs2_lr_scatter(const float* dframes, const int* dur, const int* c
 
 extern "C" int fs2_embed_bwd(const long long* ids, const float* dx, float xscale, float* demb, int M, int d, int idim,
                              int accumulate, hipStream_t stream) {
-    FS2_CHECK_ARG(ids && dx && demb && d > 0 && idim > 0 && M >= 0, "fs2_embed_bwd: bad args");
+    FS2_CHECK_ARG(ids && dx && demb && d > 0 && d <= 1024 && idim > 0 && M >= 0, "fs2_embed_bwd: bad args (d <= 1024)");
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(idim), dim3(256), 0, stream, ids, dx, xscale, demb, M, d, idim, accumulate);
     FS2_CHECK_LAUNCH("fs2_embed_bwd");
     return FS2_OK;

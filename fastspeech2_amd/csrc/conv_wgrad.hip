@@ -7,7 +7,7 @@
 //
 // GEMM view: the contraction runs over TOKENS, which is the row index of both packed matrices, so
 // both MFMA operands are the transposes of what sits in memory.  Token blocks of 64 rows of dY
-// (128-byte... 256-byte channel slices) and of X (shifted by the tap) are staged in LDS by LDS-DMA and
+// (256-byte channel slices) and of X (shifted by the tap) are staged in LDS by LDS-DMA and
 // read back TRANSPOSED (ds_read_b64_tr_b16 for bf16; scalar reads for f32): lane (g, i) receives,
 // for channel i of a 16-channel tile, tokens 4g..4g+3 and 16+4g..16+4g+3 of a 32-token fragment
 // step — the same k-slot map for both operands, so the products line up.
@@ -29,6 +29,7 @@ struct WgradArgs {
     const void* dY;      // [M, ldy] T
     const void* X;       // [M, ldx] T
     float* part;         // [ksplit][taps][N][Cin] f32
+    float* bias_part;    // [ksplit][N] f32 or null: column sums of dY (bias gradient), from the centre tap's workgroups
     const int2* seg;     // [M] or null (taps == 1)
     int M, N, Cin, taps, ldy, ldx;
     int n_tiles, c_tiles, ksplit;
@@ -122,6 +123,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int nt = 0; nt < WT; ++nt) acc[ct][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // bias gradient rides along in the centre-tap (shift 0: only the matrix tail is masked), first-c-tile
+    // workgroups: their wc == 0 waves add up the dY fragments they load anyway
+    const bool do_bias = a.bias_part && shift == 0 && c_tile == 0 && wc == 0;
+    float bsum[WT];
+#pragma unroll
+    for (int nt = 0; nt < WT; ++nt) bsum[nt] = 0.f;
+
     if (kb_lo < kb_hi) stage(kb_lo, 0);
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         __syncthreads();      // block kb landed (vmcnt(0) + barrier); every wave is done with the other stage
@@ -169,10 +177,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
                     for (int jj = 0; jj < 8; ++jj)
                         if (!((valid[ks] >> jj) & 1u)) yf[nt][jj] = (T)0.0f;
             }
+            if (do_bias) {
+#pragma unroll
+                for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) bsum[nt] += to_f32(yf[nt][jj]);
+            }
 #pragma unroll
             for (int ct = 0; ct < WT; ++ct)
 #pragma unroll
                 for (int nt = 0; nt < WT; ++nt) acc[ct][nt] = mma16(xf[ct], yf[nt], acc[ct][nt]);
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int nt = 0; nt < WT; ++nt) {
+            float t = bsum[nt];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            const int n = n0 + wn * (16 * WT) + nt * 16 + i;
+            if (g == 0 && n < a.N) a.bias_part[(size_t)blockIdx.y * a.N + n] = t;
         }
     }
 
@@ -200,9 +224,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 // grad[n][c][tap] (the nn.Conv1d / nn.Linear parameter layout) = scale * sum_s part[s][tap][n][c]
 // (+ grad when accumulate != 0)
 __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int ksplit, int taps,
-                                         long long NC, float scale, int accumulate) {
+                                         long long NC, float scale, int accumulate,
+                                         const float* __restrict__ bias_part, float* __restrict__ dbias, int N) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NC) return;
+    if (idx >= NC) {
+        const long long n = idx - NC;
+        if (dbias && n < N) {
+            float s = 0.f;
+            for (int k = 0; k < ksplit; ++k) s += bias_part[(size_t)k * N + n];
+            s *= scale;
+            dbias[n] = accumulate ? dbias[n] + s : s;
+        }
+        return;
+    }
     for (int t = 0; t < taps; ++t) {
         float s = 0.f;
         for (int k = 0; k < ksplit; ++k) s += part[((size_t)k * taps + t) * NC + idx];
@@ -217,12 +251,12 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* 
 using namespace fs2;
 
 extern "C" long long fs2_conv_wgrad_workspace(int N, int Cin, int taps, int ksplit) {
-    return (long long)ksplit * taps * N * Cin * (long long)sizeof(float);
+    return ((long long)ksplit * taps * N * Cin + (long long)ksplit * N) * (long long)sizeof(float);
 }
 
-extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float* workspace, const int* seg, int M, int N,
-                              int Cin, int taps, int ldy, int ldx, int dtype, int ksplit, float scale, int accumulate,
-                              hipStream_t stream) {
+extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float* dbias, float* workspace, const int* seg,
+                              int M, int N, int Cin, int taps, int ldy, int ldx, int dtype, int ksplit, float scale,
+                              int accumulate, hipStream_t stream) {
     FS2_CHECK_ARG(dY && X && grad && workspace, "fs2_conv_wgrad: null pointer");
     FS2_CHECK_ARG(M >= 0 && N > 0 && Cin > 0, "fs2_conv_wgrad: bad dims M=%d N=%d Cin=%d", M, N, Cin);
     FS2_CHECK_ARG(taps >= 1 && taps <= 9 && (taps & 1), "fs2_conv_wgrad: taps=%d (odd, 1..9)", taps);
@@ -235,9 +269,10 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
                   "fs2_conv_wgrad: pointers must be 16-byte aligned");
     FS2_CHECK_ARG(ksplit >= 1 && ksplit <= 64, "fs2_conv_wgrad: ksplit=%d (1..64)", ksplit);
     const long long NC = (long long)N * Cin;
+    float* bias_part = workspace + (size_t)ksplit * taps * NC;
     if (M > 0) {
         WgradArgs a;
-        a.dY = dY; a.X = X; a.part = workspace; a.seg = (const int2*)seg;
+        a.dY = dY; a.X = X; a.part = workspace; a.bias_part = dbias ? bias_part : nullptr; a.seg = (const int2*)seg;
         a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.ldy = ldy; a.ldx = ldx; a.ksplit = ksplit;
         const int bch = dtype == 0 ? 64 : 128;
         a.n_tiles = (N + bch - 1) / bch;
@@ -258,8 +293,8 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
     } else {
         (void)hipMemsetAsync(workspace, 0, (size_t)fs2_conv_wgrad_workspace(N, Cin, taps, ksplit), stream);
     }
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((NC + 255) / 256)), dim3(256), 0, stream, workspace, grad,
-                       ksplit, taps, NC, scale, accumulate);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((NC + (dbias ? N : 0) + 255) / 256)), dim3(256), 0, stream,
+                       workspace, grad, ksplit, taps, NC, scale, accumulate, bias_part, dbias, N);
     FS2_CHECK_LAUNCH("fs2_conv_wgrad(reduce)");
     return FS2_OK;
 }

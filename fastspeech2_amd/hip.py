@@ -45,7 +45,7 @@ _SIGNATURES = {
     "fs2_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "fs2_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "fs2_conv_gemm_gated": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "fs2_conv_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "fs2_conv_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "fs2_layernorm_bwd": [_P, _P, _P, _I, _L, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _P],
     "fs2_colreduce": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_rowdot_bwd": [_P, _P, _P, _I, _I, _I, _P],

@@ -48,7 +48,9 @@ class NoamOpt(object):
 
 def get_std_opt(model: torch.nn.Module, d_model, warmup, factor):
     """Adam(betas 0.9/0.98, eps 1e-9) under the Noam schedule (network/optimizer.py:57-59)."""
-    return NoamOpt(d_model, factor, warmup, torch.optim.Adam(model.parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9))
+    params = list(model.parameters())
+    fused = bool(params) and all(p.is_cuda for p in params)      # one multi-tensor kernel on the device, same update rule
+    return NoamOpt(d_model, factor, warmup, torch.optim.Adam(params, lr=0, betas=(0.9, 0.98), eps=1e-9, fused=fused))
 
 
 class ScheduledOptimizer:

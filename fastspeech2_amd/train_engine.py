@@ -270,11 +270,12 @@ class TrainEngine:
         ks = max(1, min(64, nblocks, -(-1024 // tiles)))
         return ks
 
-    def _wgrad(self, dy, x, grad, seg, M, N, Cin, taps, ldy=None, ldx=None, tag="wgrad"):
+    def _wgrad(self, dy, x, grad, seg, M, N, Cin, taps, ldy=None, ldx=None, tag="wgrad", dbias=None):
+        """weight gradient (+ bias gradient = column sums of dy when dbias is given)"""
         ks = self._wgrad_split(M, N, Cin, taps)
         ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
         t0 = self._tic(tag)
-        call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(ws), ptr(seg) if taps > 1 else None, M, N, Cin, taps,
+        call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, N, Cin, taps,
              N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
         self._toc(tag, t0, 2.0 * M * N * Cin * taps)
 
@@ -381,11 +382,11 @@ class TrainEngine:
                                        dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"])
                 dparts = None
             # ---- feed-forward: s2 = x1 + w2(relu(w1(f)))       (dy = d s2, dyt its T copy)
-            self._wgrad(dyt, r["hdn"], G[p + "feed_forward.w2.weight"], sg, M, d, U, w2.k, tag="wgrad_ffn2")
-            self._colsum(dyt, G[p + "feed_forward.w2.bias"], M, d)
+            self._wgrad(dyt, r["hdn"], G[p + "feed_forward.w2.weight"], sg, M, d, U, w2.k, tag="wgrad_ffn2",
+                        dbias=G[p + "feed_forward.w2.bias"])
             dh = self._gemm(dyt, w2.bwd, None, M, U, d, w2.k, seg=sg, gate=r["hdn"], tag="dgrad_ffn2")
-            self._wgrad(dh, r["f_t"], G[p + "feed_forward.w1.weight"], sg, M, U, d, w1.k, tag="wgrad_ffn1")
-            self._colsum(dh, G[p + "feed_forward.w1.bias"], M, U)
+            self._wgrad(dh, r["f_t"], G[p + "feed_forward.w1.weight"], sg, M, U, d, w1.k, tag="wgrad_ffn1",
+                        dbias=G[p + "feed_forward.w1.bias"])
             df = self._gemm(dh, w1.bwd, None, M, d, U, w1.k, seg=sg, out_f32=True, ksplit=self._ksplit(M, d, U, w1.k),
                             tag="dgrad_ffn1")
             if pre_ln:           # f = LN2(x1): d x1 = dy + LN2'(df)
@@ -399,17 +400,16 @@ class TrainEngine:
             if concat_after:
                 gc = G[p + "concat_linear.weight"]
                 tmp = self._empty((d, d), torch.float32)
-                self._wgrad(dyt, r["a_t"], tmp, None, M, d, d, 1)
+                self._wgrad(dyt, r["a_t"], tmp, None, M, d, d, 1, dbias=G[p + "concat_linear.bias"])
                 gc[:, :d].copy_(tmp)
                 self._wgrad(dyt, r["att"], tmp, None, M, d, d, 1)
                 gc[:, d:].copy_(tmp)
-                self._colsum(dyt, G[p + "concat_linear.bias"], M, d)
                 da_extra = self._gemm(dyt, L["wc_x"].bwd, None, M, d, d, 1, out_f32=True)
                 datt = self._gemm(dyt, L["wc_a"].bwd, None, M, d, d, 1)
             else:
                 datt = dyt
-            self._wgrad(datt, r["ctx"], G[p + "self_atten.linear_out.weight"], None, M, d, d, 1)
-            self._colsum(datt, G[p + "self_atten.linear_out.bias"], M, d)
+            self._wgrad(datt, r["ctx"], G[p + "self_atten.linear_out.weight"], None, M, d, d, 1,
+                        dbias=G[p + "self_atten.linear_out.bias"])
             dctx = self._gemm(datt, L["wo"].bwd, None, M, d, d, 1)
             dqkv = self._empty((M, 3 * d))
             delta = self._empty((self.h, M), torch.float32)
@@ -417,9 +417,9 @@ class TrainEngine:
                  ptr(cu), B, max_len, M, self.h, self.dk, 3 * d, d, self.code, stream())
             gq = G[p + "self_atten.linear_q.weight"]
             gqkv = self.flat[gq.storage_offset():gq.storage_offset() + 3 * d * d].view(3 * d, d)
-            self._wgrad(dqkv, r["a_t"], gqkv, None, M, 3 * d, d, 1)
             gb = G[p + "self_atten.linear_q.bias"]
-            self._colsum(dqkv, self.flat[gb.storage_offset():gb.storage_offset() + 3 * d], M, 3 * d)
+            self._wgrad(dqkv, r["a_t"], gqkv, None, M, 3 * d, d, 1,
+                        dbias=self.flat[gb.storage_offset():gb.storage_offset() + 3 * d])
             da = self._gemm(dqkv, L["wqkv"].bwd, None, M, d, 3 * d, 1, out_f32=True, ksplit=self._ksplit(M, d, 3 * d, 1))
             if da_extra is not None:
                 da = torch.stack([da, da_extra], 0) if da.dim() == 2 else torch.cat([da, da_extra.unsqueeze(0)], 0)
@@ -469,8 +469,7 @@ class TrainEngine:
             sg = seg if w.k > 1 else None
             _, dpre = self._ln_bwd(r["y"], dcur, dparts, P[c["p"] + "2.weight"], None, M, w.N, dw=G[c["p"] + "2.weight"],
                                    db=G[c["p"] + "2.bias"], relu_gate=True, want_f32=False)
-            self._wgrad(dpre, r["inp"], G[c["p"] + "0.conv.weight"], sg, M, w.N, cin, w.k)
-            self._colsum(dpre, G[c["p"] + "0.conv.bias"], M, w.N)
+            self._wgrad(dpre, r["inp"], G[c["p"] + "0.conv.weight"], sg, M, w.N, cin, w.k, dbias=G[c["p"] + "0.conv.bias"])
             if j == 0:
                 self._gemm(dpre, w.bwd, None, M, cin, w.N, w.k, seg=sg, res=acc, out_f32=True, out=acc)
             else:
@@ -575,8 +574,8 @@ class TrainEngine:
         dbt = self._empty((Mf, self.odim_pad))
         call("fs2_loss_grad", ptr(s["before"]), ptr(s["ys"]), None, 0, 1.0 / (Mf * self.odim), up, None, ptr(dbt), Mf,
              self.odim, self.odim_pad, self.code, stream())
-        self._wgrad(dbt, s["zt"], G["feat_out.weight"], None, Mf, self.odim, d, 1, ldy=self.odim_pad)
-        self._colsum(dbt, G["feat_out.bias"], Mf, self.odim, ldg=self.odim_pad)
+        self._wgrad(dbt, s["zt"], G["feat_out.weight"], None, Mf, self.odim, d, 1, ldy=self.odim_pad,
+                    dbias=G["feat_out.bias"])
         dz = self._gemm(dbt, self.w_out.bwd, None, Mf, d, self.odim_pad, 1, out_f32=True)
         # ---- decoder stack
         dy, dparts = self._stack_bwd(self.dec_layers, "decoder.", cfg["decoder_normalized_before"],

@@ -155,11 +155,13 @@ int fs2_conv_gemm_gated(const void* X, const void* W, const float* bias, const f
 
 /* Weight gradient of nn.Conv1d / nn.Linear (same layers as fs2_conv_gemm):
  *   grad[n][c][tap] (the parameter's own layout, fp32) = scale * sum_m dY[m, n] * X[m + tap - pad, c]
- * over token pairs inside one utterance.  MFMA GEMM over the token axis, `ksplit` token ranges
- * summed in a fixed order from `workspace` (fs2_conv_wgrad_workspace bytes). */
+ * over token pairs inside one utterance, and (dbias != NULL) the bias gradient dbias[n] = scale * sum_m dY[m, n]
+ * from the same pass.  MFMA GEMM over the token axis, `ksplit` token ranges summed in a fixed order from
+ * `workspace` (fs2_conv_wgrad_workspace bytes). */
 long long fs2_conv_wgrad_workspace(int N, int Cin, int taps, int ksplit);
-int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float* workspace, const int* seg, int M, int N, int Cin,
-                   int taps, int ldy, int ldx, int dtype, int ksplit, float scale, int accumulate, hipStream_t stream);
+int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float* dbias, float* workspace, const int* seg, int M,
+                   int N, int Cin, int taps, int ldy, int ldx, int dtype, int ksplit, float scale, int accumulate,
+                   hipStream_t stream);
 
 /* LayerNorm backward (network/utils.py:39-47) fused with the residual-gradient adds of
  * EncoderLayer.forward (network/encoder.py:171-187):  g = dy + sum_p parts[p];

@@ -70,17 +70,21 @@ def test_conv_wgrad_and_dgrad(dtype, taps, cin, n, lens, ksplit):
     xd, dyd, wsrc = x.to(DEV, tdt).contiguous(), dy.to(DEV, tdt).contiguous(), w.to(DEV).contiguous()
     # ---- weight gradient, parameter layout (n, cin, taps)
     grad = torch.full((n, cin, taps), 7.0, device=DEV)
+    dbias = torch.full((n,), 7.0, device=DEV)
     ws = _ws(hip.load().fs2_conv_wgrad_workspace(n, cin, taps, ksplit))
-    call("fs2_conv_wgrad", ptr(dyd), ptr(xd), ptr(grad), ptr(ws), ptr(seg) if taps > 1 else None, M, n, cin, taps,
-         n, cin, code, ksplit, 0.5, 0, stream())
+    call("fs2_conv_wgrad", ptr(dyd), ptr(xd), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, n, cin,
+         taps, n, cin, code, ksplit, 0.5, 0, stream())
     exp = 0.5 * wr.grad
+    expb = 0.5 * dy.double().sum(0)                # bias gradient: column sums of dY
     tol = 2e-5 if dtype == "fp32" else 1e-4       # operands already bf16-exact: only accumulation order differs
     err = (grad.cpu().double() - exp).abs().max().item()
     assert err <= tol * max(1.0, exp.abs().max().item()), err
-    call("fs2_conv_wgrad", ptr(dyd), ptr(xd), ptr(grad), ptr(ws), ptr(seg) if taps > 1 else None, M, n, cin, taps,
-         n, cin, code, ksplit, 0.5, 1, stream())                       # accumulate: doubles
+    assert (dbias.cpu().double() - expb).abs().max().item() <= tol * max(1.0, expb.abs().max().item())
+    call("fs2_conv_wgrad", ptr(dyd), ptr(xd), ptr(grad), None, ptr(ws), ptr(seg) if taps > 1 else None, M, n, cin, taps,
+         n, cin, code, ksplit, 0.5, 1, stream())                       # accumulate: doubles; no bias this time
     err = (grad.cpu().double() - 2 * exp).abs().max().item()
     assert err <= 2 * tol * max(1.0, exp.abs().max().item()), err
+    assert (dbias.cpu().double() - expb).abs().max().item() <= tol * max(1.0, expb.abs().max().item())
     # ---- packing + input gradient = conv over flipped / transposed weights
     wf = torch.empty((taps, n, cin), device=DEV, dtype=tdt)
     wb = torch.empty((taps, cin, n), device=DEV, dtype=tdt)
