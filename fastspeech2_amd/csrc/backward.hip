@@ -377,11 +377,16 @@ extern "C" int fs2_layernorm_bwd(const float* x, const float* dy, const float* p
                            part_stride, w, dres, relu_gate, dx_f32, (float*)dx_t, part, M, C, eps);
     FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
     if (w) {
-        // part is [blocks][2][C]: gamma and beta sums finish in two strided passes
-        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, stream, part, dw, blocks, C,
-                           (long long)2 * C, 1.0f, accumulate);
-        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, stream, part + C, db, blocks, C,
-                           (long long)2 * C, 1.0f, accumulate);
+        // part is [blocks][2][C]: one pass when db sits right behind dw, else two strided passes
+        if (db == dw + C) {
+            hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(2 * C, 64)), dim3(1024), 0, stream, part, dw, blocks, 2 * C,
+                               (long long)2 * C, 1.0f, accumulate);
+        } else {
+            hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, stream, part, dw, blocks, C,
+                               (long long)2 * C, 1.0f, accumulate);
+            hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk(C, 64)), dim3(1024), 0, stream, part + C, db, blocks, C,
+                               (long long)2 * C, 1.0f, accumulate);
+        }
         FS2_CHECK_LAUNCH("fs2_layernorm_bwd(finish)");
     }
     return FS2_OK;

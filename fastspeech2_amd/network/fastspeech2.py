@@ -135,10 +135,26 @@ class _TrainStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss):
+        """Parameter gradients are handed over WITHOUT a copy: `p.grad` becomes a view into the engine's flat
+        gradient buffer (the buffer the data-parallel reducer all-reduces), which the next backward
+        overwrites — after `zero_grad()` (set_to_none, the torch default) that is invisible.  If gradients
+        are still held (accum_grad > 1, run/train_decode.py:94-102) the old values are added back."""
+        eng = ctx.eng
         up = grad_loss.detach().reshape(1).to(torch.float32).contiguous()
-        G = ctx.eng.backward(ctx.saved, up)
+        params = [(n, eng.P[n]) for n in ctx.names if eng.P[n].requires_grad]
+        held = [(n, p) for n, p in params if p.grad is not None]
+        aliased = any(p.grad.data_ptr() == eng.G[n].data_ptr() for n, p in held)
+        keep = eng.flat.clone() if aliased else None
+        G = eng.backward(ctx.saved, up)
         ctx.saved = None
-        return (None, None, None, None) + tuple(G[n] for n in ctx.names)
+        if keep is not None:
+            eng.flat.add_(keep)
+        for n, p in params:
+            if p.grad is None:
+                p.grad = G[n]
+            elif p.grad.data_ptr() != G[n].data_ptr():
+                p.grad.add_(G[n])
+        return (None, None, None, None) + (None,) * len(ctx.names)
 
 
 class FeedForwardTransformer(nn.Module):

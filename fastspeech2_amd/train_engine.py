@@ -267,7 +267,9 @@ class TrainEngine:
         bch = 64 if self.code == F32 else 128
         tiles = -(-N // bch) * -(-Cin // bch) * taps
         nblocks = max(1, -(-M // 64))
-        ks = max(1, min(64, nblocks, -(-1024 // tiles)))
+        # two workgroups fit a CU (64 KB of LDS each): aim at whole rounds of 512 resident workgroups
+        target = 512 if tiles <= 512 else 1024
+        ks = max(1, min(64, nblocks, target // tiles if tiles <= target else 1))
         return ks
 
     def _wgrad(self, dy, x, grad, seg, M, N, Cin, taps, ldy=None, ldx=None, tag="wgrad", dbias=None):
