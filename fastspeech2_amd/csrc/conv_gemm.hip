@@ -452,9 +452,17 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const bool small = big_blocks < 200;   // would leave most of the 256 CUs idle: use 64x64 tiles
     if (!dma) return small ? launch_conv_gemm<T, 2, 2, 2, 0, true, 2>(a, stream) : launch_conv_gemm<T, 4, 4, 2, 0, true, 2>(a, stream);
     if (small) return launch_conv_gemm<T, 2, 2, 2, 1, false, 4>(a, stream);
-    // 128x128, X image single-buffered: 50 KB of LDS -> 3 workgroups per CU.  Measured on MI355X (config-2
+    // 128x128 (MT = 4), X image single-buffered: 50 KB of LDS -> 3 workgroups per CU.  Measured on MI355X (config-2
     // decoder FFN, bf16, random data): 128.1 us vs 154 us for the double-buffered-X / 2 WG per CU form,
     // 155 us for the 3-stage ring (MODE 2), 145-180 us for 8-wave 128x128 / 256x128 and 128x64 tiles.
+    // Narrow outputs (N <= 256, e.g. the second FFN conv) give fewer workgroups than the 768 that can be resident:
+    // 96-row tiles spread them over the CUs more evenly (measured 157 vs 167 us on 25 k x 256 x 9216; 128 rows
+    // stay better everywhere else, 64 rows nowhere).  FS2_CONV_MT=2|3|4 forces a tile height (experiments).
+    static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
+    int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
+    if (forced) best = forced;
+    if (best == 3) return launch_conv_gemm<T, 3, 4, 2, 1, false, 3>(a, stream);
+    if (best == 2) return launch_conv_gemm<T, 2, 4, 2, 1, false, 3>(a, stream);
     return launch_conv_gemm<T, 4, 4, 2, 1, false, 3>(a, stream);
 }
 
