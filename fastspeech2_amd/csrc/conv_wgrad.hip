@@ -38,27 +38,35 @@ struct WgradArgs {
 typedef __attribute__((address_space(3))) void wg_lds_void;
 typedef const __attribute__((address_space(1))) void wg_gbl_void;
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+// TW = taps per workgroup: 4 TW waves; wave (wt, wn, wc) owns the 64 x 64 quadrant (wn, wc) of tap (group * TW + wt).
+// The dY block and ONE X block with TW - 1 extra rows serve all TW taps (shifted row views), which cuts the
+// operand traffic per MFMA by TW.  TW = 3 for 3 | taps (12 waves, one workgroup per CU), else 1 (two per CU).
+template <typename T, int TW>
+__global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(WgradArgs a) {
     typedef typename Frag<T>::type frag_t;
     constexpr int EPS = 16 / (int)sizeof(T);              // elements per 16-byte slot
     constexpr int BCH = WG_ROWB / (int)sizeof(T);         // channels per tile side: 128 bf16 / 64 f32
     constexpr int WT = BCH / 32;                          // 16-channel tiles per wave per side: 4 / 2
-    constexpr int PIECES = WG_TILE_BYTES / 1024;          // 16 DMA pieces (4 rows each) per operand tile
+    constexpr int PIECES = WG_TILE_BYTES / 1024;          // 16 DMA pieces (4 rows each) of the dY tile
+    constexpr int XPIECES = (WG_KT + TW - 1 + 3) / 4;     // X tile: 64 + TW - 1 rows
+    constexpr int STAGE_BYTES = (PIECES + XPIECES) * 1024;
+    constexpr int NWAVES = 4 * TW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // stage s: dY image at smem + s * 2 * TILE, X image right behind it
+    // stage s: dY image at smem + s * STAGE_BYTES, X image right behind it
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 1, wc = wave & 1;
+    const int wt = wave >> 2, wn = (wave >> 1) & 1, wc = wave & 1;
     const int g = lane >> 4, i = lane & 15;
 
     int bx = blockIdx.x;
     const int c_tile = bx % a.c_tiles; bx /= a.c_tiles;
     const int n_tile = bx % a.n_tiles;
-    const int tap = bx / a.n_tiles;
-    const int shift = tap - ((a.taps - 1) >> 1);
+    const int tap0 = (bx / a.n_tiles) * TW;               // first tap of this workgroup's group
+    const int tap = tap0 + wt;
+    const int pad = (a.taps - 1) >> 1;
+    const int shift = tap - pad, shift0 = tap0 - pad;
     const int n0 = n_tile * BCH, c0 = c_tile * BCH;
 
     const int nblocks = (a.M + WG_KT - 1) / WG_KT;
@@ -70,23 +78,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const T* __restrict__ X = (const T*)a.X;
 
     auto stage = [&](int kb, int st) __attribute__((always_inline)) {
-        unsigned char* ydst = smem + st * 2 * WG_TILE_BYTES;
+        unsigned char* ydst = smem + st * STAGE_BYTES;
         unsigned char* xdst = ydst + WG_TILE_BYTES;
         const int mb = kb * WG_KT;
-        for (int p = wave; p < PIECES; p += 4) {
-            const int row = 4 * p + (lane >> 4);
+        for (int p = wave; p < PIECES + XPIECES; p += NWAVES) {
+            const bool isx = p >= PIECES;
+            const int q = isx ? p - PIECES : p;
+            const int row = 4 * q + (lane >> 4);
             const int slot = lane & 15;
             const int src = (slot + 16 - ((2 * row) & 15)) & 15;     // LDS slot holds global chunk (slot - rot)
-            int my = mb + row;
-            my = my < a.M ? my : a.M - 1;                            // tail tokens are masked in the fragments
-            int mx = mb + row + shift;
-            mx = mx < 0 ? 0 : (mx >= a.M ? a.M - 1 : mx);
-            int cy = n0 + src * EPS;
-            cy = cy <= a.ldy - EPS ? cy : a.ldy - EPS;               // channels beyond the matrix are never stored
-            int cx = c0 + src * EPS;
-            cx = cx <= a.ldx - EPS ? cx : a.ldx - EPS;
-            __builtin_amdgcn_global_load_lds((wg_gbl_void*)(dY + (size_t)my * a.ldy + cy), (wg_lds_void*)(ydst + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((wg_gbl_void*)(X + (size_t)mx * a.ldx + cx), (wg_lds_void*)(xdst + p * 1024), 16, 0, 0);
+            if (!isx) {
+                int my = mb + row;
+                my = my < a.M ? my : a.M - 1;                        // tail tokens are masked in the fragments
+                int cy = n0 + src * EPS;
+                cy = cy <= a.ldy - EPS ? cy : a.ldy - EPS;           // channels beyond the matrix are never stored
+                __builtin_amdgcn_global_load_lds((wg_gbl_void*)(dY + (size_t)my * a.ldy + cy), (wg_lds_void*)(ydst + q * 1024), 16, 0, 0);
+            } else {
+                int mx = mb + row + shift0;                          // image row r <-> token mb + shift0 + r
+                mx = mx < 0 ? 0 : (mx >= a.M ? a.M - 1 : mx);
+                int cx = c0 + src * EPS;
+                cx = cx <= a.ldx - EPS ? cx : a.ldx - EPS;
+                __builtin_amdgcn_global_load_lds((wg_gbl_void*)(X + (size_t)mx * a.ldx + cx), (wg_lds_void*)(xdst + q * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
         __syncthreads();      // block kb landed (vmcnt(0) + barrier); every wave is done with the other stage
         if (kb + 1 < kb_hi) stage(kb + 1, (kb + 1 - kb_lo) & 1);
-        const unsigned char* ys = smem + ((kb - kb_lo) & 1) * 2 * WG_TILE_BYTES;
+        const unsigned char* ys = smem + ((kb - kb_lo) & 1) * STAGE_BYTES;
         const unsigned char* xs = ys + WG_TILE_BYTES;
         const int mb = kb * WG_KT;
 
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int nt = 0; nt < WT; ++nt) yf[nt] = load_frag(ys, wn * (16 * WT) + nt * 16, ks * 32);
 #pragma unroll
-            for (int ct = 0; ct < WT; ++ct) xf[ct] = load_frag(xs, wc * (16 * WT) + ct * 16, ks * 32);
+            for (int ct = 0; ct < WT; ++ct) xf[ct] = load_frag(xs, wc * (16 * WT) + ct * 16, ks * 32 + wt);
             if (edge) {
 #pragma unroll
                 for (int nt = 0; nt < WT; ++nt)
@@ -277,18 +290,29 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
         const int bch = dtype == 0 ? 64 : 128;
         a.n_tiles = (N + bch - 1) / bch;
         a.c_tiles = (Cin + bch - 1) / bch;
-        const int lds = 2 * 2 * WG_TILE_BYTES;
+        const bool tw3 = taps % 3 == 0;
+        const int lds = 2 * (WG_TILE_BYTES + ((WG_KT + (tw3 ? 2 : 0) + 3) / 4) * 1024);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            const int big = 2 * (WG_TILE_BYTES + 17 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
             attr_set = true;
         }
-        dim3 grid(a.n_tiles * a.c_tiles * taps, ksplit);
-        if (dtype == 0)
-            hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, stream, a);
-        else
-            hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, stream, a);
+        dim3 grid(a.n_tiles * a.c_tiles * (tw3 ? taps / 3 : taps), ksplit);
+        if (tw3) {
+            if (dtype == 0)
+                hipLaunchKernelGGL((conv_wgrad_kernel<float, 3>), grid, dim3(768), lds, stream, a);
+            else
+                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3>), grid, dim3(768), lds, stream, a);
+        } else {
+            if (dtype == 0)
+                hipLaunchKernelGGL((conv_wgrad_kernel<float, 1>), grid, dim3(256), lds, stream, a);
+            else
+                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 1>), grid, dim3(256), lds, stream, a);
+        }
         FS2_CHECK_LAUNCH("fs2_conv_wgrad");
     } else {
         (void)hipMemsetAsync(workspace, 0, (size_t)fs2_conv_wgrad_workspace(N, Cin, taps, ksplit), stream);

@@ -265,10 +265,11 @@ class TrainEngine:
 
     def _wgrad_split(self, M, N, Cin, taps):
         bch = 64 if self.code == F32 else 128
-        tiles = -(-N // bch) * -(-Cin // bch) * taps
+        tw3 = taps % 3 == 0                      # 3 taps per 12-wave workgroup, one per CU; else 4 waves, two per CU
+        tiles = -(-N // bch) * -(-Cin // bch) * (taps // 3 if tw3 else taps)
         nblocks = max(1, -(-M // 64))
-        # two workgroups fit a CU (64 KB of LDS each): aim at whole rounds of 512 resident workgroups
-        target = 512 if tiles <= 512 else 1024
+        slots = 256 if tw3 else 512              # resident workgroups per round
+        target = slots if tiles <= slots else 2 * slots
         ks = max(1, min(64, nblocks, target // tiles if tiles <= target else 1))
         return ks
 
