@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Training-step benchmark, BASELINE.json config 5: the BASELINE architecture, 32 utterances per GPU,
 teacher-forced durations ds ~ randint(1, 13), ys/ps/es ~ N(0, 1); one step = forward + backward +
-(N > 1: bucketed RCCL gradient all-reduce overlapped with the backward) + clip + Adam (Noam schedule).
+(N > 1: bucketed RCCL gradient all-reduce overlapped with the backward) + clip + Adam (Noam schedule),
+dropout on at the reference's rates (counter-based masks; --no-dropout for the deterministic step).
 
     python bench_train.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... bench_train.py --gpus N)
@@ -54,6 +55,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--breakdown", action="store_true", help="per-tag kernel times (HIP events) of one extra step")
+    ap.add_argument("--no-dropout", action="store_true", help="deterministic step (every dropout site off)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -72,6 +74,7 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.bench_state_dict().items()}, strict=True)
     model.to(dev).train()
     model.set_precision(args.dtype)
+    model.dropout_enabled = not args.no_dropout
     eng = model.train_engine()
     reducer = GradReducer(eng) if world > 1 else None
     optimizer = get_std_opt(model, kw["adim"], 4000, 1.0)
@@ -133,7 +136,9 @@ def main():
                        "frames_per_step": frames, "params": nparams, "final_loss": round(loss, 5),
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
                        "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4),
-                       "dropout": "not applied"},
+                       "dropout": "off" if args.no_dropout else
+                       "on (reference rates: decoder 0.1 / pos 0.1 / attention 0.1, duration predictor 0.1, "
+                       "pitch+energy predictors 0.5, encoder 0)"},
             "breakdown": breakdown,
         }
         print(json.dumps(line), flush=True)

@@ -29,6 +29,7 @@ struct AttnArgs {
     float scale_log2e;   // log2(e) / sqrt(dk)
     float* lse;          // [H][M] or null: log2-domain log-sum-exp of the scaled scores (saved for the backward)
     int M;
+    Dropout drop;        // training: dropout of the probabilities (network/encoder.py:86); site = drop.stream + head
 };
 
 typedef __attribute__((address_space(3))) void at_lds_void;
@@ -190,6 +191,18 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             frag_t pf[QT];
+            if (a.drop.thresh) {      // the row sum above used the undropped p: softmax first, dropout after
+                Dropout dh = a.drop;
+                dh.stream += (uint32_t)h;
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t qg = (uint32_t)(r0 + qrow[t]);
+                        s[t][2 * c][r] *= drop_mul(dh, qg, (uint32_t)(k0 + (2 * c) * 16 + 4 * g + r));
+                        s[t][2 * c + 1][r] *= drop_mul(dh, qg, (uint32_t)(k0 + (2 * c + 1) * 16 + 4 * g + r));
+                    }
+            }
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -300,7 +313,7 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
 using namespace fs2;
 
 static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
-                           int dk, int ld, int ldo, int dtype, hipStream_t stream) {
+                           int dk, int ld, int ldo, int dtype, Dropout drop, hipStream_t stream) {
     FS2_CHECK_ARG(qkv && ctx && cu && B > 0 && n_heads > 0, "fs2_attention: bad args");
     FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_attention: dtype=%d", dtype);
     FS2_CHECK_ARG(dk == 32 || dk == 64 || dk == 96 || dk == 128, "fs2_attention: head dim %d unsupported (32/64/96/128)",
@@ -311,7 +324,7 @@ static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu
     FS2_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "fs2_attention: unaligned pointers");
     if (max_len <= 0) return FS2_OK;
     AttnArgs a;
-    a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M;
+    a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M; a.drop = drop;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dk);
 #define FS2_ATT(TT, DKK) return launch_attention<TT, DKK>(a, B, n_heads, max_len, stream)
     if (dtype == 0) {
@@ -330,14 +343,18 @@ static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu
 
 extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
                              int ldo, int dtype, hipStream_t stream) {
-    return attention_entry(qkv, ctx, nullptr, cu, B, max_len, 0, n_heads, dk, ld, ldo, dtype, stream);
+    return attention_entry(qkv, ctx, nullptr, cu, B, max_len, 0, n_heads, dk, ld, ldo, dtype, fs2_make_dropout(0, 0, 0.f),
+                           stream);
 }
 
 // Training forward: as fs2_attention, and saves lse[h][m] (log2 domain, M = total rows) for fs2_attention_bwd.
 extern "C" int fs2_attention_fwd(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M,
-                                 int n_heads, int dk, int ld, int ldo, int dtype, hipStream_t stream) {
+                                 int n_heads, int dk, int ld, int ldo, int dtype, unsigned seed, unsigned stream_id,
+                                 float rate, hipStream_t stream) {
     FS2_CHECK_ARG(lse && M >= 0, "fs2_attention_fwd: null lse");
-    return attention_entry(qkv, ctx, lse, cu, B, max_len, M, n_heads, dk, ld, ldo, dtype, stream);
+    FS2_CHECK_ARG(rate >= 0.f && rate < 1.f, "fs2_attention_fwd: dropout rate must be in [0, 1)");
+    return attention_entry(qkv, ctx, lse, cu, B, max_len, M, n_heads, dk, ld, ldo, dtype,
+                           fs2_make_dropout(seed, stream_id, rate), stream);
 }
 
 extern "C" int fs2_attention_dump(const void* qkv, float* atten, int row0, int len, int n_heads, int dk, int ld,

@@ -34,6 +34,7 @@ struct AttnBwdArgs {
     int ld, ldo, d, M;
     float scale_log2e;   // log2(e) / sqrt(dk)
     float scale;         // 1 / sqrt(dk)
+    Dropout drop;        // the forward's probability dropout (site = drop.stream + head), recomputed here
 };
 
 typedef __attribute__((address_space(3))) void ab_lds_void;
@@ -158,6 +159,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dq_kernel(AttnBwdArgs 
     f32x4 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Dropout dh = a.drop;
+    dh.stream += (uint32_t)h;
 
     const int ntiles = (len + AB_BT - 1) / AB_BT;
     auto stage = [&](int kt, int st) __attribute__((always_inline)) {
@@ -191,9 +194,12 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dq_kernel(AttnBwdArgs 
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool ok = (k0 + nt * 16 + 4 * g + r) < len;
+                const int key = k0 + nt * 16 + 4 * g + r;
+                const bool ok = key < len;
                 const float p = ok ? __builtin_amdgcn_exp2f(s[nt][r] * a.scale_log2e - lse_q) : 0.f;
-                s[nt][r] = p * (dp[nt][r] - del_q);
+                float dpv = dp[nt][r];
+                if (a.drop.thresh) dpv *= drop_mul(dh, (uint32_t)(r0 + qc), (uint32_t)key);   // dP = (dO V^T) o mask
+                s[nt][r] = p * (dpv - del_q);
             }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -255,6 +261,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
     f32x4 dk_[DT], dv_[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) dk_[dt] = dv_[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Dropout dh = a.drop;
+    dh.stream += (uint32_t)h;
 
     const int ntiles = (len + AB_BT - 1) / AB_BT;
     auto stage = [&](int qt, int st) __attribute__((always_inline)) {
@@ -291,8 +299,9 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
                 const bool ok = q < len;
                 const int qc = ok ? q : len - 1;
                 const float p = ok ? __builtin_amdgcn_exp2f(s[nt][r] * a.scale_log2e - lse[qc]) : 0.f;
-                dp[nt][r] = p * (dp[nt][r] - delta[qc]);
-                s[nt][r] = p;
+                const float mul = a.drop.thresh ? drop_mul(dh, (uint32_t)(r0 + qc), (uint32_t)kc) : 1.0f;
+                dp[nt][r] = p * (dp[nt][r] * mul - delta[qc]);
+                s[nt][r] = p * mul;                      // dV uses the dropped probabilities
             }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -348,7 +357,8 @@ using namespace fs2;
 
 extern "C" int fs2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
                                  void* dqkv, const int* cu, int B, int max_len, int M, int n_heads, int dk, int ld, int ldo,
-                                 int dtype, hipStream_t stream) {
+                                 int dtype, unsigned seed, unsigned stream_id, float rate, hipStream_t stream) {
+    FS2_CHECK_ARG(rate >= 0.f && rate < 1.f, "fs2_attention_bwd: dropout rate must be in [0, 1)");
     FS2_CHECK_ARG(qkv && ctx && dctx && lse && delta && dqkv && cu && B > 0 && n_heads > 0 && M >= 0,
                   "fs2_attention_bwd: bad args");
     FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_attention_bwd: dtype=%d", dtype);
@@ -373,6 +383,7 @@ extern "C" int fs2_attention_bwd(const void* qkv, const void* ctx, const void* d
     a.ld = ld; a.ldo = ldo; a.d = d; a.M = M;
     a.scale = 1.0f / sqrtf((float)dk);
     a.scale_log2e = 1.4426950408889634f * a.scale;
+    a.drop = fs2_make_dropout(seed, stream_id, rate);
 #define FS2_ATTB(TT, DKK) return launch_attention_bwd<TT, DKK>(a, B, n_heads, max_len, stream)
     if (dtype == 0) {
         if (dk == 32) FS2_ATTB(float, 32);

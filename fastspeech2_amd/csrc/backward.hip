@@ -20,7 +20,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             long long part_stride, const float* __restrict__ w,
                                                             const float* __restrict__ dres, int relu_gate,
                                                             float* __restrict__ dx_f32, T* __restrict__ dx_t,
-                                                            float* __restrict__ wb_part, int M, int C, float eps) {
+                                                            float* __restrict__ wb_part, int M, int C, float eps,
+                                                            Dropout din, Dropout dto) {
+    // din: the forward applied dropout to this LayerNorm's OUTPUT (or, with w == null, to the tensor whose gradient
+    // is summed here): the incoming gradient g is masked first.  dto: only the T copy of dx is masked — it is the
+    // gradient of a dropped-out sub-layer output (residual + dropout(f(x))), while the fp32 dx flows to the residual.
     __shared__ float red[4][2][LNB_MAXV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cv = C >> 2;
@@ -40,6 +44,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             if (j < cv) {
                 f32x4 t = dy ? *(const f32x4*)(dy + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+                if (din.thresh) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[r] *= drop_mul(din, (uint32_t)row, (uint32_t)(j * 4 + r));
+                }
                 gv[k] = t;
                 if (x) {
                     xv[k] = *(const f32x4*)(x + roff + j * 4);
@@ -102,7 +110,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                     for (int r = 0; r < 4; ++r) o[r] = xv[k][r] > 0.f ? o[r] : 0.f;
                 }
                 if (dx_f32) *(f32x4*)(dx_f32 + roff + j * 4) = o;
-                if (dx_t) store4<T>(dx_t + roff + j * 4, o);
+                if (dx_t) {
+                    if (dto.thresh) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] *= drop_mul(dto, (uint32_t)row, (uint32_t)(j * 4 + r));
+                    }
+                    store4<T>(dx_t + roff + j * 4, o);
+                }
             }
         }
     }
@@ -352,7 +366,12 @@ extern "C" long long fs2_layernorm_bwd_workspace(int M, int C) {
 extern "C" int fs2_layernorm_bwd(const float* x, const float* dy, const float* parts, int nparts, long long part_stride,
                                  const float* w, const float* dres, int relu_gate, float* dx_f32, void* dx_t,
                                  float* dw, float* db, float* workspace, int M, int C, float eps, int accumulate,
-                                 int dtype, hipStream_t stream) {
+                                 int dtype, unsigned seed, unsigned in_stream, float in_rate, unsigned t_stream,
+                                 float t_rate, hipStream_t stream) {
+    FS2_CHECK_ARG(in_rate >= 0.f && in_rate < 1.f && t_rate >= 0.f && t_rate < 1.f, "fs2_layernorm_bwd: rates in [0, 1)");
+    FS2_CHECK_ARG(!(t_rate > 0.f) || (dx_t && (dx_f32 || dtype == 1)),
+                  "fs2_layernorm_bwd: a masked T copy needs a separate unmasked fp32 output");
+    const Dropout din = fs2_make_dropout(seed, in_stream, in_rate), dto = fs2_make_dropout(seed, t_stream, t_rate);
     FS2_CHECK_ARG((dy || nparts > 0) && (nparts == 0 || parts), "fs2_layernorm_bwd: no incoming gradient");
     FS2_CHECK_ARG(dx_f32 || dx_t, "fs2_layernorm_bwd: nothing to write");
     FS2_CHECK_ARG(!w || (x && dw && db && workspace), "fs2_layernorm_bwd: LayerNorm mode needs x, dw, db and a workspace");
@@ -371,10 +390,10 @@ extern "C" int fs2_layernorm_bwd(const float* x, const float* dy, const float* p
     float* part = w ? workspace : nullptr;
     if (dtype == 1)
         hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, x, dy, parts, nparts,
-                           part_stride, w, dres, relu_gate, dx_f32, (bf16_t*)dx_t, part, M, C, eps);
+                           part_stride, w, dres, relu_gate, dx_f32, (bf16_t*)dx_t, part, M, C, eps, din, dto);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, x, dy, parts, nparts,
-                           part_stride, w, dres, relu_gate, dx_f32, (float*)dx_t, part, M, C, eps);
+                           part_stride, w, dres, relu_gate, dx_f32, (float*)dx_t, part, M, C, eps, din, dto);
     FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
     if (w) {
         // part is [blocks][2][C]: one pass when db sits right behind dw, else two strided passes

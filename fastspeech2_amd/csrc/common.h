@@ -75,7 +75,37 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- dropout (training only) --------------------------------------------------------------
+// Counter-based: element (row, col) of dropout site `stream` is kept iff hash(seed, stream, row, col) >= thresh,
+// thresh = rate * 2^32; kept values are scaled by 1 / (1 - rate) (nn.Dropout).  The same function is
+// evaluated again in the backward kernels, so no mask is stored.  thresh == 0 disables the site.
+struct Dropout {
+    uint32_t seed, stream, thresh;
+    float inv_keep;
+};
+
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t stream, uint32_t row, uint32_t col) {
+    uint32_t x = (row * 0x9E3779B1u) ^ ((col + 0x7F4A7C15u) * 0x85EBCA77u) ^ seed ^ (stream * 0xC2B2AE3Du);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+// multiplier of element (row, col): 0 or 1 / (1 - rate)
+__device__ __forceinline__ float drop_mul(const Dropout& d, uint32_t row, uint32_t col) {
+    return drop_hash(d.seed, d.stream, row, col) >= d.thresh ? d.inv_keep : 0.f;
+}
+
 }  // namespace fs2
+
+// host side: Dropout from (seed, stream, rate)
+static inline fs2::Dropout fs2_make_dropout(unsigned seed, unsigned stream, float rate) {
+    fs2::Dropout d;
+    d.seed = seed; d.stream = stream;
+    if (!(rate > 0.f)) { d.thresh = 0u; d.inv_keep = 1.f; return d; }
+    double t = (double)rate * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    d.inv_keep = 1.0f / (1.0f - rate);
+    return d;
+}
 
 // ---- error codes of the C ABI (include/fs2_hip.h) -----------------------------------------
 #define FS2_OK 0

@@ -36,8 +36,10 @@ struct ConvGemmArgs {
     const void* W;       // [taps][N][Cin] T
     const float* bias;   // [N] or null
     const float* res;    // [M, ldr] f32 or null
-    const void* gate;    // [M, ldg] T or null: out = gate > 0 ? out : 0 (ReLU backward through the saved activation)
-    int ldg;
+    const void* gate;    // [M, ldg] T or null: out = gate > 0 ? out * gate_scale : 0 (ReLU [+ dropout] backward
+    int ldg;             //                     through the saved activation)
+    float gate_scale;
+    Dropout drop;        // training: dropout after the activation (FFN inner dropout, network/encoder.py:30,:44)
     void* out;           // [M, ldo]  f32 (out_f32 != 0) or T
     const int2* seg;     // [M] (start,end) row range of the row's utterance; null when taps == 1
     int M, N, Cin, taps;
@@ -346,6 +348,12 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[nt][r] = tanhf(v[nt][r]);
             }
+            if (a.drop.thresh) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[nt][r] *= drop_mul(a.drop, (uint32_t)mc, (uint32_t)(ncl[nt] + r));
+            }
             if (a.gate) {
                 const T* gp = (const T*)a.gate + mc * a.ldg;
 #pragma unroll
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                     else
                         *(f32x4*)g4 = *(const f32x4*)(gp + ncl[nt]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[nt][r] = to_f32(g4[r]) > 0.f ? v[nt][r] : 0.f;
+                    for (int r = 0; r < 4; ++r) v[nt][r] = to_f32(g4[r]) > 0.f ? v[nt][r] * a.gate_scale : 0.f;
                 }
             }
             if (a.res) {
@@ -414,7 +422,8 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                     if (bias) s += bias[n];
                     if (a.relu == 1) s = fmaxf(s, 0.f);
                     if (a.relu == 2) s = tanhf(s);
-                    if (a.gate && !(to_f32(((const T*)a.gate)[(size_t)m * a.ldg + n]) > 0.f)) s = 0.f;
+                    if (a.drop.thresh) s *= drop_mul(a.drop, (uint32_t)m, (uint32_t)n);
+                    if (a.gate) s = to_f32(((const T*)a.gate)[(size_t)m * a.ldg + n]) > 0.f ? s * a.gate_scale : 0.f;
                     if (a.res) s += a.res[(size_t)m * a.ldr + n];
                     const size_t oidx = (size_t)blockIdx.y * a.split_stride + (size_t)m * a.ldo + n;
                     if (a.out_f32)
@@ -470,9 +479,9 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 
 // dtype: 0 = f32, 1 = bf16 (include/fs2_hip.h)
 static int conv_gemm_entry(const void* X, const void* W, const float* bias, const float* res, const void* gate,
-                           void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldg,
-                           int ldo, int relu, int out_f32, int dtype, int ksplit, long long split_stride,
-                           hipStream_t stream) {
+                           float gate_scale, void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr,
+                           int ldg, int ldo, int relu, int out_f32, int dtype, int ksplit, long long split_stride,
+                           fs2::Dropout drop, hipStream_t stream) {
     using namespace fs2;
     FS2_CHECK_ARG(!gate || (ldg >= N && ((uintptr_t)gate & 15) == 0 && ksplit == 1),
                   "fs2_conv_gemm_gated: gate needs ldg >= N, 16-byte alignment and ksplit == 1");
@@ -495,7 +504,7 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
                   "fs2_conv_gemm: split-K partial outputs take no relu / residual and need split_stride >= M*ldo");
     if (M == 0) return FS2_OK;
     ConvGemmArgs a;
-    a.X = X; a.W = W; a.bias = bias; a.res = res; a.gate = gate; a.ldg = ldg; a.out = out; a.seg = (const int2*)seg;
+    a.X = X; a.W = W; a.bias = bias; a.res = res; a.gate = gate; a.ldg = ldg; a.gate_scale = gate_scale; a.drop = drop; a.out = out; a.seg = (const int2*)seg;
     a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.ldx = ldx; a.ldr = ldr; a.ldo = ldo;
     a.relu = relu; a.out_f32 = out_f32; a.n_tiles = 1;
     a.ksplit = ksplit; a.split_stride = ksplit > 1 ? split_stride : 0;
@@ -506,16 +515,26 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
                              const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
                              int relu /* activation: 0 none, 1 ReLU, 2 tanh */, int out_f32, int dtype, int ksplit,
                              long long split_stride, hipStream_t stream) {
-    return conv_gemm_entry(X, W, bias, res, nullptr, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, out_f32, dtype,
-                           ksplit, split_stride, stream);
+    return conv_gemm_entry(X, W, bias, res, nullptr, 1.f, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, out_f32, dtype,
+                           ksplit, split_stride, fs2_make_dropout(0, 0, 0.f), stream);
 }
 
-// Input gradient of a conv / linear whose input was a ReLU output: the same implicit GEMM over the
-// flipped, transposed weights, with the ReLU derivative applied from the saved activation `gate`.
+// Training forward of a conv / linear followed by dropout: out = dropout(act(conv(X) + bias)) (no residual, no split-K).
+extern "C" int fs2_conv_gemm_dropout(const void* X, const void* W, const float* bias, void* out, const int* seg, int M,
+                                     int N, int Cin, int taps, int ldx, int ldo, int relu, int out_f32, int dtype,
+                                     unsigned seed, unsigned stream_id, float rate, hipStream_t stream) {
+    FS2_CHECK_ARG(rate >= 0.f && rate < 1.f, "fs2_conv_gemm_dropout: rate must be in [0, 1)");
+    return conv_gemm_entry(X, W, bias, nullptr, nullptr, 1.f, out, seg, M, N, Cin, taps, ldx, 0, 0, ldo, relu, out_f32,
+                           dtype, 1, 0, fs2_make_dropout(seed, stream_id, rate), stream);
+}
+
+// Input gradient of a conv / linear whose input was a ReLU (+ dropout) output: the same implicit GEMM over the
+// flipped, transposed weights, then out = gate > 0 ? out * gate_scale : 0 with the saved activation as `gate`
+// (a dropped element was saved as 0, so the gate covers both; gate_scale = 1 / (1 - rate)).
 extern "C" int fs2_conv_gemm_gated(const void* X, const void* W, const float* bias, const float* res, const void* gate,
-                                   void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldg,
-                                   int ldo, int out_f32, int dtype, hipStream_t stream) {
+                                   float gate_scale, void* out, const int* seg, int M, int N, int Cin, int taps, int ldx,
+                                   int ldr, int ldg, int ldo, int out_f32, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(gate, "fs2_conv_gemm_gated: null gate");
-    return conv_gemm_entry(X, W, bias, res, gate, out, seg, M, N, Cin, taps, ldx, ldr, ldg, ldo, 0, out_f32, dtype, 1, 0,
-                           stream);
+    return conv_gemm_entry(X, W, bias, res, gate, gate_scale, out, seg, M, N, Cin, taps, ldx, ldr, ldg, ldo, 0, out_f32,
+                           dtype, 1, 0, fs2_make_dropout(0, 0, 0.f), stream);
 }

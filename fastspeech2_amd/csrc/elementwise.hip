@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
                                                             int nparts, long long part_stride,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             float* sum_out, float* out_f32, T* __restrict__ out_t,
-                                                            int M, int C, float eps) {
+                                                            int M, int C, float eps, Dropout dparts, Dropout dout) {
+    // dparts: dropout of the sub-layer output sum_p parts[p] before the residual add (network/encoder.py:178,:185);
+    // dout: dropout of the LayerNorm output (predictors, network/variance_adaptor.py:75,:111).  Training only.
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -80,7 +82,14 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
         const int j = lane + k * 64;
         if (j < cv) {
             f32x4 t = x ? *(const f32x4*)(x + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+            if (dparts.thresh) {
+                f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < nparts; ++p) ps += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] += ps[r] * drop_mul(dparts, (uint32_t)row, (uint32_t)(j * 4 + r));
+            } else {
+                for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+            }
             v[k] = t;
             if (sum_out) *(f32x4*)(sum_out + roff + j * 4) = t;
             s += (t[0] + t[1]) + (t[2] + t[3]);
@@ -110,6 +119,10 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
+            if (dout.thresh) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] *= drop_mul(dout, (uint32_t)row, (uint32_t)(j * 4 + r));
+            }
             if (out_f32) *(f32x4*)(out_f32 + roff + j * 4) = o;
             if (out_t) store4<T>(out_t + roff + j * 4, o);
         }
@@ -347,6 +360,20 @@ __global__ void pack_padded_kernel(const float* __restrict__ src, const int2* __
     dst[idx] = src[((size_t)b * Tmax + (m - cu[b])) * C + c];
 }
 
+// x = dropout(x) in place (fp32), optional T copy — positional dropout (network/encoder.py:128,:145)
+template <typename T>
+__global__ void dropout_kernel(float* __restrict__ x, T* __restrict__ out_t, int M, int C, Dropout dp) {
+    const int cv = C >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * cv) return;
+    const int m = (int)(idx / cv), c = (int)(idx % cv) * 4;
+    f32x4 v = *(const f32x4*)(x + (size_t)m * C + c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= drop_mul(dp, (uint32_t)m, (uint32_t)(c + r));
+    *(f32x4*)(x + (size_t)m * C + c) = v;
+    if (out_t) store4<T>(out_t + (size_t)m * C + c, v);
+}
+
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long long n) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,9 +411,9 @@ extern "C" int fs2_embed_posenc(const long long* ids, const int* pos, const floa
     return FS2_OK;
 }
 
-extern "C" int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
-                                 const float* b, float* sum_out, float* out_f32, void* out_t, int M, int C, float eps,
-                                 int dtype, hipStream_t stream) {
+static int add_layernorm_entry(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
+                               const float* b, float* sum_out, float* out_f32, void* out_t, int M, int C, float eps,
+                               int dtype, Dropout dparts, Dropout dout, hipStream_t stream) {
     FS2_CHECK_ARG((x || nparts > 0) && (nparts == 0 || parts), "fs2_add_layernorm: no input");
     FS2_CHECK_ARG((w && b && (out_f32 || out_t)) || (!w && sum_out), "fs2_add_layernorm: nothing to write");
     FS2_CHECK_ARG(nparts >= 0 && nparts <= 16 && (nparts <= 1 || part_stride >= (long long)M * C),
@@ -396,11 +423,44 @@ extern "C" int fs2_add_layernorm(const float* x, const float* parts, int nparts,
     if (M <= 0) return FS2_OK;
     if (dtype == 1)
         hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
-                           part_stride, w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps);
+                           part_stride, w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps, dparts, dout);
     else
         hipLaunchKernelGGL(add_layernorm_kernel<float>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
-                           part_stride, w, b, sum_out, out_f32, (float*)out_t, M, C, eps);
+                           part_stride, w, b, sum_out, out_f32, (float*)out_t, M, C, eps, dparts, dout);
     FS2_CHECK_LAUNCH("fs2_add_layernorm");
+    return FS2_OK;
+}
+
+extern "C" int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
+                                 const float* b, float* sum_out, float* out_f32, void* out_t, int M, int C, float eps,
+                                 int dtype, hipStream_t stream) {
+    const Dropout off = fs2_make_dropout(0, 0, 0.f);
+    return add_layernorm_entry(x, parts, nparts, part_stride, w, b, sum_out, out_f32, out_t, M, C, eps, dtype, off, off,
+                               stream);
+}
+
+extern "C" int fs2_add_layernorm_dropout(const float* x, const float* parts, int nparts, long long part_stride,
+                                         const float* w, const float* b, float* sum_out, float* out_f32, void* out_t, int M,
+                                         int C, float eps, int dtype, unsigned seed, unsigned parts_stream,
+                                         float parts_rate, unsigned out_stream, float out_rate, hipStream_t stream) {
+    FS2_CHECK_ARG(parts_rate >= 0.f && parts_rate < 1.f && out_rate >= 0.f && out_rate < 1.f,
+                  "fs2_add_layernorm_dropout: rates must be in [0, 1)");
+    return add_layernorm_entry(x, parts, nparts, part_stride, w, b, sum_out, out_f32, out_t, M, C, eps, dtype,
+                               fs2_make_dropout(seed, parts_stream, parts_rate), fs2_make_dropout(seed, out_stream, out_rate),
+                               stream);
+}
+
+extern "C" int fs2_dropout(float* x, void* out_t, int M, int C, unsigned seed, unsigned stream_id, float rate, int dtype,
+                           hipStream_t stream) {
+    FS2_CHECK_ARG(x && C > 0 && C % 4 == 0 && rate >= 0.f && rate < 1.f, "fs2_dropout: bad args");
+    if (M <= 0) return FS2_OK;
+    const Dropout dp = fs2_make_dropout(seed, stream_id, rate);
+    const long long n = (long long)M * (C / 4);
+    if (dtype == 1)
+        hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, (bf16_t*)out_t, M, C, dp);
+    else
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, (float*)out_t, M, C, dp);
+    FS2_CHECK_LAUNCH("fs2_dropout");
     return FS2_OK;
 }
 

@@ -5,7 +5,7 @@ when a kernel is requested, this module raises — it never routes around the HI
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_uint, c_void_p
 
 import torch
 
@@ -23,7 +23,7 @@ class HipError(RuntimeError):
 _lib = None
 
 # name -> argtypes (all return int); mirrors include/fs2_hip.h
-_P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
+_P, _I, _F, _L, _U = c_void_p, c_int, c_float, c_longlong, c_uint
 _SIGNATURES = {
     "fs2_build_seg": [_P, _I, _P, _P, _I, _P],
     "fs2_embed_posenc": [_P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P],
@@ -42,11 +42,14 @@ _SIGNATURES = {
     "fs2_pack_padded": [_P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _P, _L, _I, _P],
     # training path
-    "fs2_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "fs2_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "fs2_conv_gemm_gated": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_attention_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _U, _U, _F, _P],
+    "fs2_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _U, _U, _F, _P],
+    "fs2_conv_gemm_gated": [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_conv_gemm_dropout": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _U, _U, _F, _P],
+    "fs2_add_layernorm_dropout": [_P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _I, _U, _U, _F, _U, _F, _P],
+    "fs2_dropout": [_P, _P, _I, _I, _U, _U, _F, _I, _P],
     "fs2_conv_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "fs2_layernorm_bwd": [_P, _P, _P, _I, _L, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _P],
+    "fs2_layernorm_bwd": [_P, _P, _P, _I, _L, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _U, _U, _F, _U, _F, _P],
     "fs2_colreduce": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_rowdot_bwd": [_P, _P, _P, _I, _I, _I, _P],
     "fs2_lr_scatter": [_P, _P, _P, _P, _P, _I, _P, _F, _P, _I, _I, _P],

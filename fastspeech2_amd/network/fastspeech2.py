@@ -204,6 +204,13 @@ class FeedForwardTransformer(nn.Module):
         self.reduction_factor = reduction_factor
         self.use_masking = use_masking
         self.reporter = Reporter()
+        # nn.Dropout rates of the reference's sub-modules (training path only; network/fastspeech2.py:122-167)
+        self.dropout_rates = dict(enc=transformer_enc_dropout_rate, enc_pos=transformer_enc_positional_dropout_rate,
+                                  enc_att=transformer_enc_atten_dropout_rate, dec=transformer_dec_dropout_rate,
+                                  dec_pos=transformer_dec_positional_dropout_rate,
+                                  dec_att=transformer_dec_atten_dropout_rate, dur=duration_predictor_dropout_rate,
+                                  var=0.5, pitch_embed=pitch_embed_dropout, energy_embed=energy_embed_dropout)
+        self.dropout_enabled = True       # False: deterministic training step (no dropout)
         self.cfg = dict(
             idim=idim, odim=odim, adim=adim, aheads=aheads, positionwise_layer_type=positionwise_layer_type,
             positionwise_conv_kernel_size=positionwise_conv_kernel_size, eunits=eunits, elayers=elayers,

@@ -3,8 +3,9 @@
 Forward follows `FeedForwardTransformer.forward` / `_forward` (network/fastspeech2.py:187-295) and
 `VarianceAdaptor.forward` (network/variance_adaptor.py:178-193, repair D8); backward is what
 `loss.backward()` (run/train_decode.py:94-97) computes through those modules, written out as an
-explicit sequence of C-ABI launches (include/fs2_hip.h "Training path").  Dropout is not applied
-(the step is deterministic; rates must be regarded as 0 — DESIGN.md §7).
+explicit sequence of C-ABI launches (include/fs2_hip.h "Training path").  Dropout (every nn.Dropout of the
+reference's encoder / decoder / predictors) is counter based: masks are re-derived from (step seed, site, row,
+col) in the backward kernels, nothing is stored; `model.dropout_enabled = False` gives the deterministic step.
 
 Weights stay in the model's fp32 `nn.Parameter`s (the optimiser's master copy).  Every step the
 GEMM operands are re-packed from them by `fs2_pack_weight` into persistent buffers: `fwd`
@@ -48,6 +49,8 @@ class _Weight:
 
 
 class TrainEngine:
+    SITE_ENC_POS, SITE_DEC_POS = (2 << 16) + 1, (2 << 16) + 2
+
     def __init__(self, model, dtype: str = "fp32"):
         self.dev = hip.require_gpu()
         hip.load()
@@ -80,6 +83,15 @@ class TrainEngine:
         self.odim_pad = -(-self.odim // self.epv) * self.epv
         self._build_weights()
         self._build_grad_buffer()
+        # dropout sites (rates of the reference's constructor; 0 disables a site).  model.dropout_enabled = False
+        # switches every site off (deterministic step, used for the parity tests against eval-mode goldens)
+        self.rates = dict(model.dropout_rates)
+        for k in ("pitch_embed", "energy_embed"):
+            if self.rates.get(k, 0.0) > 0.0:
+                raise NotImplementedError("dropout inside the variance embeddings is not built (reference default 0.0)")
+        self.base_seed = 0x5EED
+        self.step = 0
+        self.seed = 0
         self._pe = None
         self.grad_ready: Optional[Callable[[int], None]] = None   # called with the index of a finished bucket
         self.grad_finish: Optional[Callable[[], None]] = None     # called when every bucket has been announced
@@ -116,9 +128,9 @@ class TrainEngine:
         self.enc_layers = self._stack_weights("encoder.", cfg["elayers"], cfg["encoder_concat_after"])
         self.dec_layers = self._stack_weights("decoder.", cfg["dlayers"], cfg["decoder_concat_after"])
         va = "variance_adaptor."
-        self.dur_pred = self._pred_weights(va + "duration_predictor.")
-        self.pitch_pred = self._pred_weights(va + "pitch_predictor.")
-        self.energy_pred = self._pred_weights(va + "energy_predictor.")
+        self.dur_pred = dict(self._pred_weights(va + "duration_predictor."), rate_key="dur", site=(2 << 16) + 16)
+        self.pitch_pred = dict(self._pred_weights(va + "pitch_predictor."), rate_key="var", site=(2 << 16) + 32)
+        self.energy_pred = dict(self._pred_weights(va + "energy_predictor."), rate_key="var", site=(2 << 16) + 48)
         self.w_out = _Weight([self.P["feat_out.weight"]], self.tdt, self.dev, pad_n=self.odim_pad)
         wp, we = self.P[va + "pitch_embed.conv.conv.weight"], self.P[va + "energy_embed.conv.conv.weight"]
         if wp.shape[-1] != 1 or we.shape[-1] != 1:
@@ -214,16 +226,24 @@ class TrainEngine:
             ks -= 1
         return ks
 
+    def _rate(self, key):
+        return float(self.rates.get(key, 0.0)) if self.drop_on else 0.0
+
     def _gemm(self, x, w, bias, M, N, Cin, taps, seg=None, res=None, relu=0, out_f32=False, ksplit=1, out=None,
-              ldx=None, gate=None, tag=None):
+              ldx=None, gate=None, gate_scale=1.0, drop=None, tag=None):
+        """drop = (site, rate): dropout after the activation (training forward)"""
         if out is None:
             shape = (ksplit, M, N) if ksplit > 1 else (M, N)
             out = self._empty(shape, dtype=torch.float32 if out_f32 else self.tdt)
         ldx = Cin if ldx is None else ldx
         t0 = self._tic(tag)
         if gate is not None:
-            call("fs2_conv_gemm_gated", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(gate), ptr(out), ptr(seg), M, N, Cin,
-                 taps, ldx, N, N, N, int(out_f32), self.code, stream())
+            call("fs2_conv_gemm_gated", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(gate), float(gate_scale), ptr(out),
+                 ptr(seg), M, N, Cin, taps, ldx, N, N, N, int(out_f32), self.code, stream())
+        elif drop is not None and drop[1] > 0.0:
+            assert res is None and ksplit == 1
+            call("fs2_conv_gemm_dropout", ptr(x), ptr(w), ptr(bias), ptr(out), ptr(seg), M, N, Cin, taps, ldx, N,
+                 int(relu), int(out_f32), self.code, self.seed, drop[0], drop[1], stream())
         else:
             call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps, ldx, N, N,
                  int(relu), int(out_f32), self.code, ksplit, M * N, stream())
@@ -244,24 +264,37 @@ class TrainEngine:
         e1.record()
         self.profile.append((tag, flops, e0, e1))
 
-    def _ln(self, x, w, b, M, C, want_f32, want_t, parts=None, sum_out=None):
+    def _ln(self, x, w, b, M, C, want_f32, want_t, parts=None, sum_out=None, pdrop=None, odrop=None):
+        """pdrop / odrop = (site, rate): dropout of the summed parts / of the LayerNorm output"""
         of = self._empty((M, C), torch.float32) if (want_f32 or (want_t and self.code == F32)) else None
         ot = self._empty((M, C)) if (want_t and self.code != F32) else None
         nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
-        call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
-             M, C, LN_EPS, self.code, stream())
+        pd = pdrop if (pdrop is not None and pdrop[1] > 0.0 and nparts > 0) else (0, 0.0)
+        od = odrop if (odrop is not None and odrop[1] > 0.0) else (0, 0.0)
+        if pd[1] > 0.0 or od[1] > 0.0:
+            call("fs2_add_layernorm_dropout", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of),
+                 ptr(ot), M, C, LN_EPS, self.code, self.seed, pd[0], pd[1], od[0], od[1], stream())
+        else:
+            call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
+                 M, C, LN_EPS, self.code, stream())
         return of, (of if self.code == F32 else ot)
 
-    def _ln_bwd(self, x, dy, parts, w, dres, M, C, dw=None, db=None, relu_gate=False, want_f32=True, want_t=True):
-        """returns (dx fp32 or None, dx as T or None)"""
+    def _ln_bwd(self, x, dy, parts, w, dres, M, C, dw=None, db=None, relu_gate=False, want_f32=True, want_t=True,
+                in_drop=None, t_drop=None):
+        """returns (dx fp32 or None, dx as T or None).  in_drop = (site, rate) masks the incoming gradient,
+        t_drop masks only the T copy (the gradient of a dropped-out sub-layer output)."""
         f32 = self.code == F32
-        of = self._empty((M, C), torch.float32) if (want_f32 or (want_t and f32)) else None
-        ot = self._empty((M, C)) if (want_t and not f32) else None
+        ind = in_drop if (in_drop is not None and in_drop[1] > 0.0) else (0, 0.0)
+        td = t_drop if (t_drop is not None and t_drop[1] > 0.0 and want_t) else (0, 0.0)
+        split_t = td[1] > 0.0                      # the T copy differs from the fp32 result
+        of = self._empty((M, C), torch.float32) if (want_f32 or (want_t and f32) or split_t) else None
+        ot = self._empty((M, C)) if (want_t and (not f32 or split_t)) else None
         nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
         ws = self._ws(hip.load().fs2_layernorm_bwd_workspace(M, C)) if w is not None else None
         call("fs2_layernorm_bwd", ptr(x), ptr(dy), ptr(parts), nparts, M * C, ptr(w), ptr(dres), int(relu_gate), ptr(of),
-             ptr(ot), ptr(dw), ptr(db), ptr(ws), M, C, LN_EPS, 0, self.code, stream())
-        return of, (of if f32 else ot)
+             ptr(ot), ptr(dw), ptr(db), ptr(ws), M, C, LN_EPS, 0, self.code, self.seed, ind[0], ind[1], td[0], td[1],
+             stream())
+        return of, (ot if ot is not None else of)
 
     def _wgrad_split(self, M, N, Cin, taps):
         bch = 64 if self.code == F32 else 128
@@ -302,16 +335,25 @@ class TrainEngine:
             w.pack(self.code)
 
     # ------------------------------------------------------------------ forward pieces
+    @staticmethod
+    def _sites(side, li):
+        """dropout site ids of one FFT block: attention probabilities (+ head), attention residual, FFN inner, FFN residual"""
+        base = (0 if side == "enc" else 1 << 16) + 256 * (li + 1)
+        return dict(att=base, res_a=base + 64, inner=base + 65, res_f=base + 66)
+
     def _stack_fwd(self, layers, prefix, pre_ln, concat_after, x32, xt, seg, cu, B, max_len, M):
         d, P = self.d, self.P
-        recs, pend = [], None
-        for L in layers:
+        side = "enc" if prefix.startswith("enc") else "dec"
+        r_res, r_att = self._rate(side), self._rate(side + "_att")
+        recs, pend, pend_drop = [], None, None
+        for li, L in enumerate(layers):
             p = L["prefix"]
+            st = self._sites(side, li)
             r = {}
             if pre_ln:
                 xs = x32 if pend is None else self._empty((M, d), torch.float32)
                 a_t = self._ln(x32, P[p + "norm1.weight"], P[p + "norm1.bias"], M, d, False, True, parts=pend,
-                               sum_out=xs if pend is not None else None)[1]
+                               sum_out=xs if pend is not None else None, pdrop=pend_drop)[1]
                 x32 = xs
                 r["x_ln1"] = x32
             else:
@@ -321,7 +363,7 @@ class TrainEngine:
             ctx = self._empty((M, d))
             lse = self._empty((self.h, M), torch.float32)
             call("fs2_attention_fwd", ptr(qkv), ptr(ctx), ptr(lse), ptr(cu), B, max_len, M, self.h, self.dk, 3 * d, d,
-                 self.code, stream())
+                 self.code, self.seed, st["att"], r_att, stream())
             r.update(qkv=qkv, ctx=ctx, lse=lse)
             if concat_after:
                 att = self._gemm(ctx, L["wo"].fwd, P[p + "self_atten.linear_out.bias"], M, d, d, 1)
@@ -332,29 +374,32 @@ class TrainEngine:
             else:
                 pend = self._gemm(ctx, L["wo"].fwd, P[p + "self_atten.linear_out.bias"], M, d, d, 1, out_f32=True,
                                   ksplit=self._ksplit(M, d, d, 1))
+            pend_drop = (st["res_a"], r_res)
             if pre_ln:
                 x1 = self._empty((M, d), torch.float32)
                 f_t = self._ln(x32, P[p + "norm2.weight"], P[p + "norm2.bias"], M, d, False, True, parts=pend,
-                               sum_out=x1)[1]
+                               sum_out=x1, pdrop=pend_drop)[1]
                 x32 = x1
                 r["x_ln2"] = x1
             else:
                 s1 = self._empty((M, d), torch.float32)
                 x32, xt = self._ln(x32, P[p + "norm1.weight"], P[p + "norm1.bias"], M, d, True, True, parts=pend,
-                                   sum_out=s1)
+                                   sum_out=s1, pdrop=pend_drop)
                 r["s1"] = s1
                 f_t = xt
             r["f_t"] = f_t
             w1, w2 = L["w1"], L["w2"]
             sg = seg if w1.k > 1 else None
-            hdn = self._gemm(f_t, w1.fwd, P[p + "feed_forward.w1.bias"], M, w1.N, d, w1.k, seg=sg, relu=1, tag="ffn1")
+            hdn = self._gemm(f_t, w1.fwd, P[p + "feed_forward.w1.bias"], M, w1.N, d, w1.k, seg=sg, relu=1, tag="ffn1",
+                             drop=(st["inner"], r_res))
             pend = self._gemm(hdn, w2.fwd, P[p + "feed_forward.w2.bias"], M, d, w1.N, w2.k, seg=sg, out_f32=True,
                               ksplit=self._ksplit(M, d, w1.N, w2.k), tag="ffn2")
+            pend_drop = (st["res_f"], r_res)
             r["hdn"] = hdn
             if not pre_ln:
                 s2 = self._empty((M, d), torch.float32)
                 x32, xt = self._ln(x32, P[p + "norm2.weight"], P[p + "norm2.bias"], M, d, True, True, parts=pend,
-                                   sum_out=s2)
+                                   sum_out=s2, pdrop=pend_drop)
                 r["s2"] = s2
                 pend = None
             recs.append(r)
@@ -362,42 +407,50 @@ class TrainEngine:
         if pre_ln:
             after = self._empty((M, d), torch.float32)
             x32, xt = self._ln(x32, P[prefix + "after_norm.weight"], P[prefix + "after_norm.bias"], M, d, True, True,
-                               parts=pend, sum_out=after)
+                               parts=pend, sum_out=after, pdrop=pend_drop)
         return x32, xt, dict(layers=recs, after=after)
 
     def _stack_bwd(self, layers, prefix, pre_ln, concat_after, saved, dy, dparts, seg, cu, B, max_len, M, first_ready):
         """dy (+ dparts): gradient wrt the stack output.  Returns the gradient wrt the stack input as (dy, parts).
         first_ready: gradient bucket that is complete once the stack's after_norm has been processed."""
         d, P, G = self.d, self.P, self.G
+        side = "enc" if prefix.startswith("enc") else "dec"
+        r_res, r_att = self._rate(side), self._rate(side + "_att")
+        inner_scale = 1.0 / (1.0 - r_res) if r_res > 0.0 else 1.0
+        n = len(layers)
         if pre_ln:
             dy, dyt = self._ln_bwd(saved["after"], dy, dparts, P[prefix + "after_norm.weight"], None, M, d,
-                                   dw=G[prefix + "after_norm.weight"], db=G[prefix + "after_norm.bias"])
+                                   dw=G[prefix + "after_norm.weight"], db=G[prefix + "after_norm.bias"],
+                                   t_drop=(self._sites(side, n - 1)["res_f"], r_res))
             dparts = None
         if self.grad_ready is not None:
             self.grad_ready(first_ready)
-        for L, r in zip(reversed(layers), reversed(saved["layers"])):
+        for li in range(n - 1, -1, -1):
+            L, r = layers[li], saved["layers"][li]
+            st = self._sites(side, li)
             p = L["prefix"]
             w1, w2 = L["w1"], L["w2"]
             U = w1.N
             sg = seg if w1.k > 1 else None
             if not pre_ln:       # x2 = LN2(s2)
                 dy, dyt = self._ln_bwd(r["s2"], dy, dparts, P[p + "norm2.weight"], None, M, d,
-                                       dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"])
+                                       dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"], t_drop=(st["res_f"], r_res))
                 dparts = None
             # ---- feed-forward: s2 = x1 + w2(relu(w1(f)))       (dy = d s2, dyt its T copy)
             self._wgrad(dyt, r["hdn"], G[p + "feed_forward.w2.weight"], sg, M, d, U, w2.k, tag="wgrad_ffn2",
                         dbias=G[p + "feed_forward.w2.bias"])
-            dh = self._gemm(dyt, w2.bwd, None, M, U, d, w2.k, seg=sg, gate=r["hdn"], tag="dgrad_ffn2")
+            dh = self._gemm(dyt, w2.bwd, None, M, U, d, w2.k, seg=sg, gate=r["hdn"], gate_scale=inner_scale,
+                            tag="dgrad_ffn2")
             self._wgrad(dh, r["f_t"], G[p + "feed_forward.w1.weight"], sg, M, U, d, w1.k, tag="wgrad_ffn1",
                         dbias=G[p + "feed_forward.w1.bias"])
             df = self._gemm(dh, w1.bwd, None, M, d, U, w1.k, seg=sg, out_f32=True, ksplit=self._ksplit(M, d, U, w1.k),
                             tag="dgrad_ffn1")
             if pre_ln:           # f = LN2(x1): d x1 = dy + LN2'(df)
                 dy, dyt = self._ln_bwd(r["x_ln2"], None, df, P[p + "norm2.weight"], dy, M, d,
-                                       dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"])
+                                       dw=G[p + "norm2.weight"], db=G[p + "norm2.bias"], t_drop=(st["res_a"], r_res))
             else:                # f = x1 = LN1(s1): d s1 = LN1'(dy + df)
                 dy, dyt = self._ln_bwd(r["s1"], dy, df, P[p + "norm1.weight"], None, M, d,
-                                       dw=G[p + "norm1.weight"], db=G[p + "norm1.bias"])
+                                       dw=G[p + "norm1.weight"], db=G[p + "norm1.bias"], t_drop=(st["res_a"], r_res))
             # ---- attention: s1 = x + out(ctx)  [or x + concat_linear(cat(a, out(ctx)))]
             da_extra = None
             if concat_after:
@@ -417,7 +470,7 @@ class TrainEngine:
             dqkv = self._empty((M, 3 * d))
             delta = self._empty((self.h, M), torch.float32)
             call("fs2_attention_bwd", ptr(r["qkv"]), ptr(r["ctx"]), ptr(dctx), ptr(r["lse"]), ptr(delta), ptr(dqkv),
-                 ptr(cu), B, max_len, M, self.h, self.dk, 3 * d, d, self.code, stream())
+                 ptr(cu), B, max_len, M, self.h, self.dk, 3 * d, d, self.code, self.seed, st["att"], r_att, stream())
             gq = G[p + "self_atten.linear_q.weight"]
             gqkv = self.flat[gq.storage_offset():gq.storage_offset() + 3 * d * d].view(3 * d, d)
             gb = G[p + "self_atten.linear_q.bias"]
@@ -427,8 +480,9 @@ class TrainEngine:
             if da_extra is not None:
                 da = torch.stack([da, da_extra], 0) if da.dim() == 2 else torch.cat([da, da_extra.unsqueeze(0)], 0)
             if pre_ln:           # a = LN1(x): d x = dy + LN1'(da)
+                prev = (self._sites(side, li - 1)["res_f"], r_res) if li > 0 else None
                 dy, dyt = self._ln_bwd(r["x_ln1"], None, da, P[p + "norm1.weight"], dy, M, d,
-                                       dw=G[p + "norm1.weight"], db=G[p + "norm1.bias"])
+                                       dw=G[p + "norm1.weight"], db=G[p + "norm1.bias"], t_drop=prev)
                 dparts = None
             else:                # a = x: d x = dy + da, folded into the next LayerNorm backward
                 dparts = da
@@ -438,6 +492,7 @@ class TrainEngine:
 
     def _pred_fwd(self, pr, x_t, seg, M, cin):
         P = self.P
+        rate, site0 = self._rate(pr["rate_key"]), pr["site"]
         cur, recs = x_t, []
         n = len(pr["convs"])
         y32 = None
@@ -447,7 +502,8 @@ class TrainEngine:
                            out_f32=True)
             recs.append(dict(inp=cur, y=y))
             last = j == n - 1
-            y32, cur = self._ln(y, P[c["p"] + "2.weight"], P[c["p"] + "2.bias"], M, w.N, last, not last)
+            y32, cur = self._ln(y, P[c["p"] + "2.weight"], P[c["p"] + "2.bias"], M, w.N, last, not last,
+                                odrop=(site0 + j, rate))
             cin = w.N
         out = self._empty((M, pr["nout"]), torch.float32)
         call("fs2_rowdot", ptr(y32), ptr(P[pr["prefix"] + "linear.weight"]), ptr(P[pr["prefix"] + "linear.bias"]),
@@ -459,6 +515,7 @@ class TrainEngine:
         P, G = self.P, self.G
         pre = pr["prefix"]
         nout = pr["nout"]
+        rate, site0 = self._rate(pr["rate_key"]), pr["site"]
         C = pr["convs"][-1]["w"].N
         self._colsum(saved["y32"], G[pre + "linear.weight"], M, C, g_is_t=False, S=dout, R=nout)
         self._colsum(dout, G[pre + "linear.bias"], M, nout, g_is_t=False)
@@ -471,7 +528,7 @@ class TrainEngine:
             cin = cin0 if j == 0 else pr["convs"][j - 1]["w"].N
             sg = seg if w.k > 1 else None
             _, dpre = self._ln_bwd(r["y"], dcur, dparts, P[c["p"] + "2.weight"], None, M, w.N, dw=G[c["p"] + "2.weight"],
-                                   db=G[c["p"] + "2.bias"], relu_gate=True, want_f32=False)
+                                   db=G[c["p"] + "2.bias"], relu_gate=True, want_f32=False, in_drop=(site0 + j, rate))
             self._wgrad(dpre, r["inp"], G[c["p"] + "0.conv.weight"], sg, M, w.N, cin, w.k, dbias=G[c["p"] + "0.conv.bias"])
             if j == 0:
                 self._gemm(dpre, w.bwd, None, M, cin, w.N, w.k, seg=sg, res=acc, out_f32=True, out=acc)
@@ -485,6 +542,9 @@ class TrainEngine:
         """ids int64 [Mp], ds int32 [Mp], ps fp32 [Mf,4], es fp32 [Mf,1], ys fp32 [Mf,odim] — packed, on the device.
         Returns (loss terms as device scalars, saved state for `backward`)."""
         dev, d, P, cfg = self.dev, self.d, self.P, self.cfg
+        self.drop_on = bool(getattr(self.model, "dropout_enabled", True))
+        self.step += 1
+        self.seed = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFF
         self.refresh_weights()
         B = len(ilens)
         ilens = [int(v) for v in ilens]
@@ -509,6 +569,9 @@ class TrainEngine:
         xt = self._empty((Mp, d)) if (not enc_pre and self.code != F32) else None
         call("fs2_embed_posenc", ptr(ids), ptr(pos_p), ptr(P["encoder.embed.0.weight"]), ptr(pe), xscale, enc_alpha,
              ptr(x32), ptr(xt), Mp, d, self.idim, self.code, stream())
+        if self._rate("enc_pos") > 0.0:
+            call("fs2_dropout", ptr(x32), ptr(xt), Mp, d, self.seed, self.SITE_ENC_POS, self._rate("enc_pos"), self.code,
+                 stream())
         if self.code == F32:
             xt = x32
         hs32, hst, enc_saved = self._stack_fwd(self.enc_layers, "encoder.", enc_pre, cfg["encoder_concat_after"], x32, xt,
@@ -544,6 +607,9 @@ class TrainEngine:
              ptr(P[va + "pitch_embed.conv.conv.bias"]), ptr(P[va + "energy_embed.conv.conv.weight"]),
              ptr(P[va + "energy_embed.conv.conv.bias"]), 1.0, 1.0, ptr(pe_f), ptr(pos_f), xscale, dec_alpha, None,
              ptr(y32), ptr(yt), Mf, d, self.pdim, self.edim, self.code, stream())
+        if self._rate("dec_pos") > 0.0:
+            call("fs2_dropout", ptr(y32), ptr(yt), Mf, d, self.seed, self.SITE_DEC_POS, self._rate("dec_pos"), self.code,
+                 stream())
         if self.code == F32:
             yt = y32
         z32, zt, dec_saved = self._stack_fwd(self.dec_layers, "decoder.", dec_pre, cfg["decoder_concat_after"], y32, yt,
@@ -553,7 +619,7 @@ class TrainEngine:
                      cu_phone=cu_phone, cu_frames=cu_frames, seg_p=seg_p, seg_f=seg_f, pos_p=pos_p, pos_f=pos_f,
                      dur_used=dur_used, cum=cum, enc=enc_saved, dec=dec_saved, dur=dur_saved, pitch=pitch_saved,
                      energy=energy_saved, hst=hst, hs_lrt=hs_lrt, zt=zt, before=before, logd=logd, pitch_out=pitch,
-                     energy_out=energy, xscale=xscale, keep=(olens_dev, lr_index, hs_lr32, x32, y32, z32))
+                     energy_out=energy, xscale=xscale, seed=self.seed, drop_on=self.drop_on, keep=(olens_dev, lr_index, hs_lr32, x32, y32, z32))
         return dict(before=before, log_durations=logd.view(-1), pitch=pitch, energy=energy), saved
 
     def backward(self, s, upstream: Optional[torch.Tensor] = None):
@@ -561,6 +627,7 @@ class TrainEngine:
         MSE(pitch, ps) + MSE(energy, es), each a mean over the packed elements, times `upstream` (device scalar)."""
         d, P, G, cfg = self.d, self.P, self.G, self.cfg
         B, Mp, Mf = s["B"], s["Mp"], s["Mf"]
+        self.seed, self.drop_on = s["seed"], s["drop_on"]       # the masks of THIS step's forward
         va = "variance_adaptor."
         up = ptr(upstream) if upstream is not None else None
         self._bucket_of = {}
@@ -584,8 +651,9 @@ class TrainEngine:
         dy, dparts = self._stack_bwd(self.dec_layers, "decoder.", cfg["decoder_normalized_before"],
                                      cfg["decoder_concat_after"], s["dec"], dz, None, s["seg_f"], s["cu_frames"], B,
                                      s["max_ol"], Mf, 0)
-        if dparts is not None:      # materialise the sum
-            dy, _ = self._ln_bwd(None, dy, dparts, None, None, Mf, d, want_t=False)
+        if dparts is not None or self._rate("dec_pos") > 0.0:      # materialise the sum, undo the positional dropout
+            dy, _ = self._ln_bwd(None, dy, dparts, None, None, Mf, d, want_t=False,
+                                 in_drop=(self.SITE_DEC_POS, self._rate("dec_pos")))
         # ---- decoder positional encoding + variance embeddings (y = xscale * (hs_lr + emb) + alpha pe)
         if self.scaled:
             tmp = self._empty((d,), torch.float32)
@@ -624,8 +692,9 @@ class TrainEngine:
         dx, dparts = self._stack_bwd(self.enc_layers, "encoder.", cfg["encoder_normalized_before"],
                                      cfg["encoder_concat_after"], s["enc"], dhs, None, s["seg_p"], s["cu_phone"], B,
                                      s["max_il"], Mp, adaptor_bucket)
-        if dparts is not None:
-            dx, _ = self._ln_bwd(None, dx, dparts, None, None, Mp, d, want_t=False)
+        if dparts is not None or self._rate("enc_pos") > 0.0:
+            dx, _ = self._ln_bwd(None, dx, dparts, None, None, Mp, d, want_t=False,
+                                 in_drop=(self.SITE_ENC_POS, self._rate("enc_pos")))
         call("fs2_embed_bwd", ptr(s["ids"]), ptr(dx), float(s["xscale"]), ptr(G["encoder.embed.0.weight"]), Mp, d,
              self.idim, 0, stream())
         if self.scaled:

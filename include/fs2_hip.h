@@ -134,24 +134,51 @@ int fs2_cast(const float* src, void* dst, long long n, int dtype, hipStream_t st
  * (gradient accumulation, run/train_decode.py:94-102).
  * ------------------------------------------------------------------------------------------ */
 
+/* Dropout (nn.Dropout in training mode; network/encoder.py:30,:44,:86,:128,:145,:178,:185, network/variance_adaptor.py:75,:111)
+ * is counter based: element (row, col) of dropout site `stream_id` is kept iff
+ * hash(seed, stream_id, row, col) >= rate * 2^32 and then scaled by 1 / (1 - rate).  Backward kernels evaluate the
+ * same function again, so no mask is stored; a rate of 0 disables the site.  The random stream differs from
+ * torch's, so dropout results are statistically, not bit-wise, comparable with the reference ("parity unpinned"). */
+
 /* fs2_attention that also saves lse[h][m] (log2-domain log-sum-exp of the scaled scores,
- * [n_heads][M] fp32, M = total packed rows) for fs2_attention_bwd. */
+ * [n_heads][M] fp32, M = total packed rows) for fs2_attention_bwd, with dropout of the probabilities
+ * (site of head h = stream_id + h; row = packed query row, col = key index inside the utterance). */
 int fs2_attention_fwd(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
-                      int dk, int ld, int ldo, int dtype, hipStream_t stream);
+                      int dk, int ld, int ldo, int dtype, unsigned seed, unsigned stream_id, float rate,
+                      hipStream_t stream);
 
 /* Backward of MultiHeadedAttention's core (network/encoder.py:73-88): from qkv, ctx (forward output),
  * dctx and lse computes dqkv [M, ld] T (dq | dk | dv).  delta: fp32 scratch [n_heads][M].
  * Probabilities are recomputed per tile; every output element has one writer (deterministic). */
 int fs2_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta, void* dqkv,
                       const int* cu, int B, int max_len, int M, int n_heads, int dk, int ld, int ldo, int dtype,
-                      hipStream_t stream);
+                      unsigned seed, unsigned stream_id, float rate, hipStream_t stream);
 
-/* fs2_conv_gemm (no activation, no split-K) whose result is zeroed where gate[m, n] <= 0: the input
- * gradient of a conv / linear fed by a ReLU (`torch.relu(self.w1(x))`, network/encoder.py:29, :43),
- * computed as the same implicit GEMM over the flipped-transposed weights (fs2_pack_weight `bwd`). */
-int fs2_conv_gemm_gated(const void* X, const void* W, const float* bias, const float* res, const void* gate, void* out,
-                        const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldg, int ldo, int out_f32,
-                        int dtype, hipStream_t stream);
+/* fs2_conv_gemm (no activation, no split-K) whose result is gate[m, n] > 0 ? out * gate_scale : 0: the input
+ * gradient of a conv / linear fed by dropout(ReLU(.)) (`self.dropout(torch.relu(self.w1(x)))`,
+ * network/encoder.py:29-30, :43-44), computed as the same implicit GEMM over the flipped-transposed weights
+ * (fs2_pack_weight `bwd`); gate = the saved activation (dropped elements are 0), gate_scale = 1 / (1 - rate). */
+int fs2_conv_gemm_gated(const void* X, const void* W, const float* bias, const float* res, const void* gate,
+                        float gate_scale, void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr,
+                        int ldg, int ldo, int out_f32, int dtype, hipStream_t stream);
+
+/* out = dropout(act(conv(X) + bias)): training forward of the first FFN conv / linear (same references). */
+int fs2_conv_gemm_dropout(const void* X, const void* W, const float* bias, void* out, const int* seg, int M, int N,
+                          int Cin, int taps, int ldx, int ldo, int relu, int out_f32, int dtype, unsigned seed,
+                          unsigned stream_id, float rate, hipStream_t stream);
+
+/* fs2_add_layernorm with dropout of the summed sub-layer output before the residual add
+ * (`residual + self.dropout(sublayer(x))`, network/encoder.py:178, :185) and / or of the LayerNorm output
+ * (predictors: LayerNorm -> Dropout, network/variance_adaptor.py:74-75, :110-111). */
+int fs2_add_layernorm_dropout(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
+                              const float* b, float* sum_out, float* out_f32, void* out_t, int M, int C, float eps,
+                              int dtype, unsigned seed, unsigned parts_stream, float parts_rate, unsigned out_stream,
+                              float out_rate, hipStream_t stream);
+
+/* x = dropout(x) in place (fp32 [M, C]) with an optional T copy: positional-encoding dropout
+ * (network/encoder.py:128, :145). */
+int fs2_dropout(float* x, void* out_t, int M, int C, unsigned seed, unsigned stream_id, float rate, int dtype,
+                hipStream_t stream);
 
 /* Weight gradient of nn.Conv1d / nn.Linear (same layers as fs2_conv_gemm):
  *   grad[n][c][tap] (the parameter's own layout, fp32) = scale * sum_m dY[m, n] * X[m + tap - pad, c]
@@ -167,11 +194,15 @@ int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float* dbias, flo
  * EncoderLayer.forward (network/encoder.py:171-187):  g = dy + sum_p parts[p];
  * dx = LayerNormBackward(g; x, w) (w == NULL: dx = g) + dres; relu_gate != 0 additionally zeroes dx
  * where x <= 0 (x is the ReLU output feeding the predictors' LayerNorm, network/variance_adaptor.py:66-75).
- * dw / db receive the affine gradients.  workspace: fs2_layernorm_bwd_workspace bytes. */
+ * dw / db receive the affine gradients.  workspace: fs2_layernorm_bwd_workspace bytes.
+ * Dropout: site `in_stream` masks the incoming gradient g (the forward dropped this LayerNorm's output, or —
+ * w == NULL — the tensor whose gradient is summed here); site `t_stream` masks only the T copy dx_t, which then
+ * is the gradient of a dropped-out sub-layer output while dx_f32 stays the residual-stream gradient. */
 long long fs2_layernorm_bwd_workspace(int M, int C);
 int fs2_layernorm_bwd(const float* x, const float* dy, const float* parts, int nparts, long long part_stride,
                       const float* w, const float* dres, int relu_gate, float* dx_f32, void* dx_t, float* dw, float* db,
-                      float* workspace, int M, int C, float eps, int accumulate, int dtype, hipStream_t stream);
+                      float* workspace, int M, int C, float eps, int accumulate, int dtype, unsigned seed,
+                      unsigned in_stream, float in_rate, unsigned t_stream, float t_rate, hipStream_t stream);
 
 /* out[r][c] = scale * sum_m S[m][r] * G[m][c]  (S NULL: column sums, R = 1) — bias gradients, the
  * predictors' final-Linear and the k=1 VarianceEmbedding weight gradients.  pe != NULL:

@@ -95,9 +95,9 @@ def test_conv_wgrad_and_dgrad(dtype, taps, cin, n, lens, ksplit):
         gate = torch.randn(M, cin, generator=g)
         gd = gate.to(DEV, tdt).contiguous()
         dx = torch.empty((M, cin), device=DEV)
-        call("fs2_conv_gemm_gated", ptr(dyd), ptr(wb), None, None, ptr(gd), ptr(dx), ptr(seg) if taps > 1 else None,
+        call("fs2_conv_gemm_gated", ptr(dyd), ptr(wb), None, None, ptr(gd), 1.25, ptr(dx), ptr(seg) if taps > 1 else None,
              M, cin, n, taps, n, 0, cin, cin, 1, code, stream())
-        expx = xr.grad * (gate.to(tdt).double() > 0)
+        expx = 1.25 * xr.grad * (gate.to(tdt).double() > 0)
         err = (dx.cpu().double() - expx).abs().max().item()
         assert err <= (2e-5 if dtype == "fp32" else 2e-3) * max(1.0, expx.abs().max().item()), err
 
@@ -133,7 +133,7 @@ def test_layernorm_bwd(dtype, M, C, nparts, mode):
     ws = _ws(hip.load().fs2_layernorm_bwd_workspace(M, C))
     call("fs2_layernorm_bwd", ptr(xd), ptr(dyd), ptr(pd) if nparts else None, nparts, M * C,
          ptr(wd) if mode != "sum" else None, ptr(rd) if mode in ("pre", "sum") else None, int(mode == "relu"),
-         ptr(dx32), ptr(dxt), ptr(dw), ptr(db), ptr(ws), M, C, 1e-12, 0, code, stream())
+         ptr(dx32), ptr(dxt), ptr(dw), ptr(db), ptr(ws), M, C, 1e-12, 0, code, 0, 0, 0.0, 0, 0.0, stream())
     sc = max(1.0, exp_dx.abs().max().item())
     assert (dx32.cpu().double() - exp_dx).abs().max().item() <= 2e-5 * sc
     assert (dxt.float().cpu().double() - exp_dx).abs().max().item() <= (2e-5 if dtype == "fp32" else 1e-2) * sc
@@ -257,7 +257,8 @@ def test_attention_fwd_lse_and_bwd(dtype, h, dk, lens):
     qd, dod = qkv.to(DEV, tdt).contiguous(), dctx.to(DEV, tdt).contiguous()
     ctx = torch.empty((M, d), device=DEV, dtype=tdt)
     lse = torch.empty((h, M), device=DEV)
-    call("fs2_attention_fwd", ptr(qd), ptr(ctx), ptr(lse), ptr(cu_d), B, max(lens), M, h, dk, 3 * d, d, code, stream())
+    call("fs2_attention_fwd", ptr(qd), ptr(ctx), ptr(lse), ptr(cu_d), B, max(lens), M, h, dk, 3 * d, d, code, 0, 0, 0.0,
+         stream())
     tol = 2e-5 if dtype == "fp32" else 2e-2
     assert (ctx.float().cpu().double() - ctx_ref.detach()).abs().max().item() <= tol * max(1.0, ctx_ref.abs().max().item())
     lse_ref = torch.cat(lses, 1) / math.log(2.0)
@@ -265,7 +266,7 @@ def test_attention_fwd_lse_and_bwd(dtype, h, dk, lens):
     delta = torch.empty((h, M), device=DEV)
     dqkv = torch.full((M, 3 * d), 5.0, device=DEV, dtype=tdt)
     call("fs2_attention_bwd", ptr(qd), ptr(ctx), ptr(dod), ptr(lse), ptr(delta), ptr(dqkv), ptr(cu_d), B, max(lens), M,
-         h, dk, 3 * d, d, code, stream())
+         h, dk, 3 * d, d, code, 0, 0, 0.0, stream())
     exp = qr.grad
     err = (dqkv.float().cpu().double() - exp).abs().max().item()
     assert err <= (5e-5 if dtype == "fp32" else 3e-2) * max(1.0, exp.abs().max().item()), err

@@ -21,6 +21,7 @@ def _model(meta, dtype="fp32"):
     m.load_state_dict(helpers.golden_state_dict(meta), strict=True)
     m.to(DEV).train()
     m.set_precision(dtype)
+    m.dropout_enabled = False          # goldens / oracle are dropout-free (eval-mode reference modules)
     return m
 
 
