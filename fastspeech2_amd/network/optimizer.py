@@ -8,35 +8,36 @@ import torch
 class NoamOpt(object):
     """lr(step) = factor * model_size^-0.5 * min(step^-0.5, step * warmup^-1.5)"""
 
-    def __init__(self, model_size, factor, warmup, optimizer: torch.optim.Optimizer):
-        self.optimizer = optimizer
-        self.model_size = model_size
-        self.factor = factor
-        self.warmup = warmup
-        self._step = 0
-        self._rate = 0
+    _SCALARS = ("_step", "warmup", "factor", "model_size", "_rate")      # snapshot keys besides "optimizer"
 
-    @property
-    def param_group(self):
-        return self.optimizer.param_groups
+    def __init__(self, model_size, factor, warmup, optimizer: torch.optim.Optimizer):
+        self._step, self._rate = 0, 0
+        self.model_size, self.factor, self.warmup = model_size, factor, warmup
+        self.optimizer = optimizer
+
+    param_group = property(lambda self: self.optimizer.param_groups)
 
     def rate(self, step=None):
+        """learning rate at `step` (default: the current step count)"""
         s = self._step if step is None else step
-        return self.factor * self.model_size ** (-0.5) * min(s ** (-0.5), s * self.warmup ** (-1.5))
+        warm, decay = s * self.warmup ** (-1.5), s ** (-0.5)
+        return self.factor * self.model_size ** (-0.5) * min(decay, warm)
 
     def step(self):
+        """advance the schedule, write the rate into every param group, then step the wrapped optimiser"""
         self._step += 1
-        self._rate = self.rate()
+        lr = self._rate = self.rate()
         for group in self.optimizer.param_groups:
-            group["lr"] = self._rate
+            group["lr"] = lr
         self.optimizer.step()
 
     def zero_grad(self):
         self.optimizer.zero_grad()
 
     def state_dict(self):
-        return {"_step": self._step, "warmup": self.warmup, "factor": self.factor, "model_size": self.model_size,
-                "_rate": self._rate, "optimizer": self.optimizer.state_dict()}
+        sd = {k: getattr(self, k) for k in self._SCALARS}
+        sd["optimizer"] = self.optimizer.state_dict()
+        return sd
 
     def load_state_dict(self, state_dict: dict):
         for key, value in state_dict.items():

@@ -55,18 +55,20 @@ def decode(cfg, model, current_step=0, criterion=None, rank: int = 0, world_size
         for bucket in shard_buckets(lengths, world_size, rank, bs):
             xs = [torch.from_numpy(utts[ids[i]]) for i in bucket]
             out = model.infer_batch(xs, duration_control=dc, pitch_control=pc, energy_control=ec)
-            mel = out["mel"].cpu().numpy()
+            mel = out["mel"].cpu().numpy()                                   # after the PostNet (== before when there is none)
+            before = out["packed"]["mel_before"].cpu().numpy()
+            cu = np.concatenate([[0], np.cumsum([int(v) for v in out["olens"]])])
             for j, i in enumerate(bucket):
                 T, L = int(out["olens"][j]), lengths[i]
                 results[ids[i]] = dict(
-                    mel=mel[j, :T], mel_postnet=mel[j, :T],            # postnet is None: after == before
+                    mel=before[cu[j]:cu[j + 1]], mel_postnet=mel[j, :T],
                     durations=out["durations"][j, :L].cpu().numpy(),
                     pitch=out["pitch"][j, :T].cpu().numpy(), energy=out["energy"][j, :T].cpu().numpy(),
                     src_mask=out["src_mask"][j, :L].numpy(), mel_mask=out["mel_mask"][j, :T].numpy(),
                     mel_length=T)
     out_npz = _get(cfg, "DECODE.OUT_NPZ")
     if out_npz:
-        np.savez_compressed(out_npz, **{k: v["mel"] for k, v in results.items()})
+        np.savez_compressed(out_npz, **{k: v["mel_postnet"] for k, v in results.items()})
     if was_training:
         model.train()                                                  # run/fastspeech_decode.py:37
     return results

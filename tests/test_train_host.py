@@ -119,3 +119,68 @@ def test_two_rank_gradient_averaging():
     want = [1.5 * i for i in range(10)]          # mean of (i, 2 i)
     for _, flat in got:
         assert flat == want
+
+
+def _fake_json(n, seed):
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    data = {}
+    for i in range(n):
+        tp = int(rng.integers(5, 60))
+        data["utt%03d" % i] = {"input": [{"shape": [int(tp * rng.integers(4, 9)), 80]}], "output": [{"shape": [tp, 1]}],
+                               "category": None if i % 7 else "b"}
+    return data
+
+
+def test_batchset_rules():
+    from fastspeech2_amd.run import batchfy
+    data = _fake_json(60, 1)
+    batches = batchfy.make_batchset(data, batch_bins=200000, min_batch_size=2)
+    seen = [k for b in batches for k, _ in b]
+    assert sorted(seen) == sorted(data) and all(len(b) >= 2 for b in batches)
+    for b in batches:                                   # sorted by text length (swap_io: json "output"), longest first
+        tl = [v["output"][0]["shape"][0] for _, v in b]
+        assert tl == sorted(tl, reverse=True)
+        mx = max(v["input"][0]["shape"][0] * 80 for _, v in b)
+        assert (mx + b[0][1]["output"][0]["shape"][0]) * (len(b) - 1) <= 200000 or len(b) == 2
+    with pytest.raises(ValueError):
+        batchfy.batchfy_by_bin(sorted(data.items()), 0)
+    with pytest.raises(NotImplementedError):
+        batchfy.make_batchset(data, batch_bins=0)
+    with pytest.raises(NotImplementedError):
+        batchfy.make_batchset(data, batch_bins=10, swap_io=False)
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("bins,min_bs,short", [(200000, 1, False), (120000, 3, False), (300000, 2, True), (50000, 4, False)])
+def test_batchset_equals_reference(bins, min_bs, short):
+    if not ref_harness.available():
+        pytest.skip("reference not mounted")
+    ref_harness.load()
+    import importlib
+    ref_b = importlib.import_module("run.batchfy")
+    from fastspeech2_amd.run import batchfy
+    data = _fake_json(83, 2)
+    want = ref_b.make_batchset(data, batch_bins=bins, min_batch_size=min_bs, shortest_first=short)
+    got = batchfy.make_batchset(data, batch_bins=bins, min_batch_size=min_bs, shortest_first=short)
+    assert [[k for k, _ in b] for b in got] == [[k for k, _ in b] for b in want]
+
+
+def test_snapshot_roundtrip(tmp_path):
+    from fastspeech2_amd.run.snapshot import load_snapshot, save_snapshot
+    m = torch.nn.Linear(3, 2)
+    o = opt.get_std_opt(m, 16, 10, 1.0)
+    up = Updater(_Toy(), 1.0, o)
+    m.weight.grad, m.bias.grad = torch.ones_like(m.weight), torch.ones_like(m.bias)
+    o.step()
+    up.iteration = 7
+    path = save_snapshot(str(tmp_path / "snapshot.sp.1"), m, o, up)
+    assert sorted(torch.load(path, weights_only=True)) == ["model", "optimizer", "trainer"]
+    assert [f for f in os.listdir(tmp_path)] == ["snapshot.sp.1"]              # temporary directory removed
+    m2 = torch.nn.Linear(3, 2)
+    o2 = opt.get_std_opt(m2, 1, 1, 1.0)
+    up2 = Updater(_Toy(), 1.0, o2)
+    load_snapshot(path, m2, o2, up2)
+    assert torch.equal(m2.weight, m.weight) and o2._step == 1 and o2.warmup == 10 and up2.iteration == 7
+    st, st2 = o.optimizer.state_dict()["state"], o2.optimizer.state_dict()["state"]
+    assert torch.equal(st[0]["exp_avg"], st2[0]["exp_avg"])
