@@ -466,7 +466,9 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // 155 us for the 3-stage ring (MODE 2), 145-180 us for 8-wave 128x128 / 256x128 and 128x64 tiles.
     // Narrow outputs (N <= 256, e.g. the second FFN conv) give fewer workgroups than the 768 that can be resident:
     // 96-row tiles spread them over the CUs more evenly (measured 157 vs 167 us on 25 k x 256 x 9216; 128 rows
-    // stay better everywhere else, 64 rows nowhere).  FS2_CONV_MT=2|3|4 forces a tile height (experiments).
+    // stay better everywhere else, 64 rows nowhere; a 256 x 128 block of 128 x 64 wave tiles — fewer LDS reads
+    // per MFMA, 2 workgroups per CU — measured 145 / 202 us against 136 / 166 us on the two FFN convs: the
+    // kernel is bound by latency hiding, not by LDS bandwidth).  FS2_CONV_MT=2|3|4 forces a tile height (experiments).
     static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
     int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
     if (forced) best = forced;
