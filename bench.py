@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--encoder-dtype", default=None, choices=[None, "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="no cross-step overlap: one forward after the other")
+    ap.add_argument("--frame-streams", type=int, default=2, help="alternate the frame-level halves over this many streams")
     ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
     return ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
             for _ in range(n):
                 last = step()
         else:
-            for last in eng.forward_pipelined((ids, ilens) for _ in range(n)):
+            for last in eng.forward_pipelined(((ids, ilens) for _ in range(n)), frame_streams=args.frame_streams):
                 pass
         return last
 
@@ -177,7 +178,7 @@ def main():
                                    "frames), 4+4 FFT blocks d=256 h=2 conv-k9 U=1024, random-init, idim=odim=80",
                        "frames_per_step": frames, "phones_per_step": float(sum(ilens)) * world,
                        "encoder_dtype": args.encoder_dtype or args.dtype,
-                       "step_overlap": "none" if args.serial else "phone-level half of step k+1 on a side stream under the frame-level half of step k",
+                       "step_overlap": "none" if args.serial else "phone-level half of step k+1 on a side stream under the frame-level half of step k; frame-level halves alternate over %d stream(s)" % args.frame_streams,
                        "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
                        "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4)},

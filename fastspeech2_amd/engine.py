@@ -409,12 +409,18 @@ class Engine:
             out["enc_attention"], out["dec_attention"] = ctx["enc_att"], dec_att
         return out
 
-    def forward_pipelined(self, batches, **kw):
+    def forward_pipelined(self, batches, frame_streams: int = 1, **kw):
         """Throughput mode for a stream of batches [(ids, ilens), ...]: the phone phase of batch k+1 (small
         grids that cannot fill 256 CUs) runs on a side stream underneath the frame phase of batch k.
-        Same kernels, same results as `forward`; yields one output dict per batch, in order."""
+        frame_streams > 1 additionally alternates the frame phases over that many streams, so the tail of one
+        batch's kernels overlaps the head of the next batch's.  Same kernels, same results as `forward`;
+        yields one output dict per batch, in order (outputs of batch k are ordered after the current stream
+        only once `out["ready"]` has been waited for when frame_streams > 1)."""
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream(device=self.dev)
+            self._fstreams = []
+        while len(self._fstreams) < frame_streams:
+            self._fstreams.append(torch.cuda.Stream(device=self.dev))
         main = torch.cuda.current_stream()
         it = iter(batches)
 
@@ -426,11 +432,22 @@ class Engine:
             ctx = launch_phone(next(it))
         except StopIteration:
             return
+        k = 0
         while ctx is not None:
             nxt = next(it, None)
             nctx = launch_phone(nxt) if nxt is not None else None
-            yield self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))
+            if frame_streams > 1:
+                fs = self._fstreams[k % frame_streams]
+                fs.wait_stream(main)
+                with torch.cuda.stream(fs):
+                    out = self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))
+                    out["ready"] = torch.cuda.Event()
+                    out["ready"].record()
+                yield out
+            else:
+                yield self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))
             ctx = nctx
+            k += 1
 
     def unpack(self, packed: torch.Tensor, cu: torch.Tensor, B: int, Tmax: int) -> torch.Tensor:
         """packed [M, C] fp32 -> zero-padded [B, Tmax, C] (pad_list, network/utils.py:50-56)."""

@@ -211,9 +211,12 @@ def test_pipelined_forward_equals_serial():
         xs = [rng.integers(1, meta["cfg"]["idim"], size=int(L)) for L in rng.integers(3, 40, size=3)]
         batches.append((torch.from_numpy(np.concatenate(xs)).cuda(), [len(x) for x in xs]))
     serial = [eng.forward(ids, il) for ids, il in batches]
-    piped = list(eng.forward_pipelined(batches))
-    assert len(piped) == len(serial)
-    for a, b in zip(serial, piped):
-        assert a["olens"] == b["olens"]
-        assert torch.equal(a["durations"], b["durations"])
-        assert torch.equal(a["mel"], b["mel"])
+    for fs in (1, 2, 3):               # frame phases on one stream / alternating over 2 or 3 streams
+        piped = list(eng.forward_pipelined(batches, frame_streams=fs))
+        assert len(piped) == len(serial)
+        for a, b in zip(serial, piped):
+            if fs > 1:
+                b["ready"].synchronize()
+            assert a["olens"] == b["olens"]
+            assert torch.equal(a["durations"], b["durations"])
+            assert torch.equal(a["mel"], b["mel"])
