@@ -96,6 +96,8 @@ class TrainEngine:
         self.grad_ready: Optional[Callable[[int], None]] = None   # called with the index of a finished bucket
         self.grad_finish: Optional[Callable[[], None]] = None     # called when every bucket has been announced
         self.profile = None
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev)     # None: weight gradients on the main stream
+        self._wgrad_pending = False
 
     # ------------------------------------------------------------------ set-up
     def _stack_weights(self, prefix, n_layers, concat_after):
@@ -313,11 +315,31 @@ class TrainEngine:
     def _wgrad(self, dy, x, grad, seg, M, N, Cin, taps, ldy=None, ldx=None, tag="wgrad", dbias=None):
         """weight gradient (+ bias gradient = column sums of dy when dbias is given)"""
         ks = self._wgrad_split(M, N, Cin, taps)
-        ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
-        t0 = self._tic(tag)
-        call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, N, Cin, taps,
-             N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
-        self._toc(tag, t0, 2.0 * M * N * Cin * taps)
+        if self.wgrad_stream is None or self.profile is not None:
+            ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
+            t0 = self._tic(tag)
+            call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, N,
+                 Cin, taps, N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
+            self._toc(tag, t0, 2.0 * M * N * Cin * taps)
+            return
+        # weight gradients are leaves of the backward: they run on a side stream, beside the input-gradient
+        # chain on the main stream (ordered after the kernel that produced dy; joined before the buckets are used)
+        main, side = torch.cuda.current_stream(), self.wgrad_stream
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
+            call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, N,
+                 Cin, taps, N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
+        dy.record_stream(side)
+        x.record_stream(side)
+        self._wgrad_pending = True
+
+    def _join_wgrad(self):
+        if self.wgrad_stream is not None and self._wgrad_pending:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self._wgrad_pending = False
 
     def _colsum(self, G, out, M, C, ldg=None, g_is_t=True, S=None, R=1, scale=1.0, pe=None, pos=None):
         ws = self._ws(hip.load().fs2_colreduce_workspace(M, C, R))
@@ -428,6 +450,7 @@ class TrainEngine:
                                    t_drop=(self._sites(side, n - 1)["res_f"], r_res))
             dparts = None
         if self.grad_ready is not None:
+            self._join_wgrad()
             self.grad_ready(first_ready)
         for li in range(n - 1, -1, -1):
             L, r = layers[li], saved["layers"][li]
@@ -459,11 +482,12 @@ class TrainEngine:
             da_extra = None
             if concat_after:
                 gc = G[p + "concat_linear.weight"]
-                tmp = self._empty((d, d), torch.float32)
-                self._wgrad(dyt, r["a_t"], tmp, None, M, d, d, 1, dbias=G[p + "concat_linear.bias"])
-                gc[:, :d].copy_(tmp)
-                self._wgrad(dyt, r["att"], tmp, None, M, d, d, 1)
-                gc[:, d:].copy_(tmp)
+                tmp_x, tmp_a = self._empty((d, d), torch.float32), self._empty((d, d), torch.float32)
+                self._wgrad(dyt, r["a_t"], tmp_x, None, M, d, d, 1, dbias=G[p + "concat_linear.bias"])
+                self._wgrad(dyt, r["att"], tmp_a, None, M, d, d, 1)
+                self._join_wgrad()                      # the two halves are copied on the main stream
+                gc[:, :d].copy_(tmp_x)
+                gc[:, d:].copy_(tmp_a)
                 da_extra = self._gemm(dyt, L["wc_x"].bwd, None, M, d, d, 1, out_f32=True)
                 datt = self._gemm(dyt, L["wc_a"].bwd, None, M, d, d, 1)
             else:
@@ -491,6 +515,7 @@ class TrainEngine:
             else:                # a = x: d x = dy + da, folded into the next LayerNorm backward
                 dparts = da
             if self.grad_ready is not None:
+                self._join_wgrad()
                 self.grad_ready(self._bucket_of[p])
         return dy, dparts
 
@@ -705,6 +730,7 @@ class TrainEngine:
             tmp = self._empty((d,), torch.float32)
             self._colsum(dx, tmp, Mp, d, g_is_t=False, pe=self._pe_table(s["max_il"]), pos=s["pos_p"])
             torch.sum(tmp, 0, out=G["encoder.embed.1.alpha"])
+        self._join_wgrad()
         if self.grad_ready is not None:
             self.grad_ready(len(self.bucket_slices) - 1)
         if self.grad_finish is not None:
