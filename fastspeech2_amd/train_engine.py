@@ -347,18 +347,41 @@ class TrainEngine:
         call("fs2_colreduce", ptr(G), gd, C if ldg is None else ldg, ptr(S), 0 if S is None else S.shape[1], R, ptr(pe),
              ptr(pos), ptr(out), ptr(ws), M, C, float(scale), 0, stream())
 
-    def refresh_weights(self):
-        """Re-pack every GEMM operand from the current parameter values (call once per step)."""
-        for L, ca in [(l, self.cfg["encoder_concat_after"]) for l in self.enc_layers] + \
-                     [(l, self.cfg["decoder_concat_after"]) for l in self.dec_layers]:
+    def _pack_layers(self, layers, concat_after):
+        for L in layers:
             p = L["prefix"]
             torch.cat([self.P[p + "self_atten.linear_%s.bias" % n].data for n in "qkv"], 0, out=L["bqkv"])
-            if ca:
+            if concat_after:
                 wc = self.P[p + "concat_linear.weight"].data
                 L["wc_x"].params[0].data.copy_(wc[:, :self.d])
                 L["wc_a"].params[0].data.copy_(wc[:, self.d:])
-        for w in self._all_weights():
-            w.pack(self.code)
+            for k in ("wqkv", "wo", "w1", "w2", "wc_x", "wc_a"):
+                if k in L:
+                    L[k].pack(self.code)
+
+    def refresh_weights(self):
+        """Re-pack every GEMM operand from the current parameter values (once per step).  Two groups on a side
+        stream, in the order the forward needs them: phone level (encoder stack, duration predictor) and frame
+        level (pitch / energy predictors, decoder stack, feat_out) — the second group is packed underneath the
+        phone-level compute.  Returns the two events the forward waits for."""
+        main = torch.cuda.current_stream()
+        side = self.wgrad_stream if self.wgrad_stream is not None else main
+        if side is not main:
+            side.wait_stream(main)                 # the optimiser's update of the parameters
+        with torch.cuda.stream(side):
+            self._pack_layers(self.enc_layers, self.cfg["encoder_concat_after"])
+            for c in self.dur_pred["convs"]:
+                c["w"].pack(self.code)
+            ev_phone = torch.cuda.Event()
+            ev_phone.record()
+            for pr in (self.pitch_pred, self.energy_pred):
+                for c in pr["convs"]:
+                    c["w"].pack(self.code)
+            self._pack_layers(self.dec_layers, self.cfg["decoder_concat_after"])
+            self.w_out.pack(self.code)
+            ev_frame = torch.cuda.Event()
+            ev_frame.record()
+        return ev_phone, ev_frame
 
     # ------------------------------------------------------------------ forward pieces
     @staticmethod
@@ -574,7 +597,8 @@ class TrainEngine:
         self.drop_on = bool(getattr(self.model, "dropout_enabled", True))
         self.step += 1
         self.seed = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFF
-        self.refresh_weights()
+        ev_phone, ev_frame = self.refresh_weights()
+        torch.cuda.current_stream().wait_event(ev_phone)
         B = len(ilens)
         ilens = [int(v) for v in ilens]
         Mp = int(sum(ilens))
@@ -606,6 +630,7 @@ class TrainEngine:
         hs32, hst, enc_saved = self._stack_fwd(self.enc_layers, "encoder.", enc_pre, cfg["encoder_concat_after"], x32, xt,
                                                seg_p, cu_phone, B, max_il, Mp)
         logd, dur_saved = self._pred_fwd(self.dur_pred, hst, seg_p, Mp, d)
+        torch.cuda.current_stream().wait_event(ev_frame)          # frame-level operands are packed
         # LengthRegulator with the ground-truth durations (network/variance_adaptor.py:187)
         dur_used = self._empty((Mp,), torch.int32)
         cum = self._empty((Mp,), torch.int32)
