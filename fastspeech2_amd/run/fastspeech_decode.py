@@ -51,20 +51,30 @@ def decode(cfg, model, current_step=0, criterion=None, rank: int = 0, world_size
     was_training = model.training
     model.eval()
     results = {}
+    buckets = list(shard_buckets(lengths, world_size, rank, bs))
     with torch.no_grad():
-        for bucket in shard_buckets(lengths, world_size, rank, bs):
-            xs = [torch.from_numpy(utts[ids[i]]) for i in bucket]
-            out = model.infer_batch(xs, duration_control=dc, pitch_control=pc, energy_control=ec)
-            mel = out["mel"].cpu().numpy()                                   # after the PostNet (== before when there is none)
-            before = out["packed"]["mel_before"].cpu().numpy()
-            cu = np.concatenate([[0], np.cumsum([int(v) for v in out["olens"]])])
+        eng = model.engine()
+        # the whole list of buckets goes through the throughput path: phone-level half of bucket k+1 under the
+        # frame-level half of bucket k, frame-level halves alternating over two streams (Engine.forward_pipelined)
+        feed = []
+        for bucket in buckets:
+            xs = [utts[ids[i]] for i in bucket]
+            feed.append((torch.from_numpy(np.concatenate(xs)).to(eng.dev), [len(x) for x in xs]))
+        outs = eng.forward_pipelined(feed, frame_streams=2, duration_control=dc, pitch_control=pc, energy_control=ec)
+        for bucket, out in zip(buckets, outs):
+            out["ready"].synchronize()
+            mel = out["mel"].cpu().numpy()                                   # after the PostNet (== before without one)
+            before = out["mel_before"].cpu().numpy()
+            dur = out["durations"].cpu().numpy()
+            pitch, energy = out["pitch"].cpu().numpy(), out["energy"].cpu().numpy()
+            cu_f = np.concatenate([[0], np.cumsum(out["olens"])])
+            cu_p = np.concatenate([[0], np.cumsum([lengths[i] for i in bucket])])
             for j, i in enumerate(bucket):
                 T, L = int(out["olens"][j]), lengths[i]
+                f0, f1, p0, p1 = cu_f[j], cu_f[j + 1], cu_p[j], cu_p[j + 1]
                 results[ids[i]] = dict(
-                    mel=before[cu[j]:cu[j + 1]], mel_postnet=mel[j, :T],
-                    durations=out["durations"][j, :L].cpu().numpy(),
-                    pitch=out["pitch"][j, :T].cpu().numpy(), energy=out["energy"][j, :T].cpu().numpy(),
-                    src_mask=out["src_mask"][j, :L].numpy(), mel_mask=out["mel_mask"][j, :T].numpy(),
+                    mel=before[f0:f1], mel_postnet=mel[f0:f1], durations=dur[p0:p1].astype(np.int64),
+                    pitch=pitch[f0:f1], energy=energy[f0:f1], src_mask=np.ones(L, bool), mel_mask=np.ones(T, bool),
                     mel_length=T)
     out_npz = _get(cfg, "DECODE.OUT_NPZ")
     if out_npz:
