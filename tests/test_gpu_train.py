@@ -145,3 +145,40 @@ def test_updater_trains_and_reducer_streams():
     n_buckets = len(eng.bucket_slices)
     assert seen[:n_buckets] == list(range(n_buckets))                 # buckets are announced in flat-buffer order
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_two_process_data_parallel_step(tmp_path):
+    """Two data-parallel ranks (two processes on this GPU, gloo transport standing in for RCCL) with the bucketed
+    reducer hooked into the backward: both end with the mean of the two single-rank gradients."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    name = "train_tiny_conv3_mixed"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py"), str(tmp_path), name],
+                                      env=env, cwd=root))
+    for p in procs:
+        assert p.wait(timeout=110) == 0
+    got = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(2)]
+    # single-process truth: the two ranks' gradients computed here, then averaged
+    _, meta = helpers.load_golden(name)
+    cfg = helpers.oracle_cfg(meta)
+    want = None
+    for rank in range(2):
+        model = _model(meta)
+        model(*_ragged_batch(cfg, 100 + rank, [17 + 5 * rank, 30, 8])).backward()
+        g = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+        want = g if want is None else {k: 0.5 * (want[k] + g[k]) for k in g}
+    for k, w in want.items():
+        for r in range(2):
+            a = torch.from_numpy(got[r][k.replace(".", "__")]).double()
+            assert (a - w).abs().max().item() <= 1e-6 * max(1.0, w.abs().max().item()), (k, r)
+    assert got[0]["loss"] != got[1]["loss"]          # different shares of the data
