@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--breakdown", action="store_true", help="per-tag kernel times (HIP events) of one extra step")
     ap.add_argument("--no-dropout", action="store_true", help="deterministic step (every dropout site off)")
+    ap.add_argument("--rccl-single", action="store_true",
+                    help="with one GPU: still create the nccl (RCCL) group and run the bucketed all-reduces")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -65,9 +67,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.rccl_single:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29571")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     kw = dict(synth.BASELINE_OVERRIDES)
     model = FeedForwardTransformer(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
@@ -76,7 +83,7 @@ def main():
     model.set_precision(args.dtype)
     model.dropout_enabled = not args.no_dropout
     eng = model.train_engine()
-    reducer = GradReducer(eng) if world > 1 else None
+    reducer = GradReducer(eng, single_rank_too=args.rccl_single) if dist is not None else None
     optimizer = get_std_opt(model, kw["adim"], 4000, 1.0)
     updater = Updater(model, grad_clip=1.0, optimizer=optimizer, reducer=reducer)
     batch = make_batch(world, rank)

@@ -19,8 +19,10 @@ import torch.distributed as dist
 class GradReducer:
     """Averages the engine's flat gradient buffer across ranks, bucket by bucket."""
 
-    def __init__(self, engine, process_group=None):
+    def __init__(self, engine, process_group=None, single_rank_too: bool = False):
+        """single_rank_too: run the collectives even with one rank (exercises the RCCL path on a one-GPU box)"""
         self.engine = engine
+        self.single_rank_too = single_rank_too
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.cuda = engine.flat.is_cuda
@@ -31,13 +33,18 @@ class GradReducer:
 
     def bucket_ready(self, index: int):
         lo, hi = self.engine.bucket_slices[index]
-        if hi <= lo or self.world == 1:
+        if hi <= lo or (self.world == 1 and not self.single_rank_too):
             return
         buf = self.engine.flat[lo:hi]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record()                              # the bucket's last gradient kernel, on the compute stream
-            self.comm.wait_event(ev)
+            # order the collective after the bucket's last gradient kernels: the compute stream and, when the
+            # engine runs its weight-gradient GEMMs beside it, that stream too — without joining the two
+            streams = self.engine.producer_streams() if hasattr(self.engine, "producer_streams") else \
+                [torch.cuda.current_stream()]
+            for st in streams:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.comm.wait_event(ev)
             with torch.cuda.stream(self.comm):
                 buf.mul_(1.0 / self.world)
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -336,6 +336,13 @@ class TrainEngine:
         x.record_stream(side)
         self._wgrad_pending = True
 
+    def producer_streams(self):
+        """streams whose enqueued work writes the gradient buffer (a bucket consumer must order itself after both)"""
+        out = [torch.cuda.current_stream()]
+        if self.wgrad_stream is not None:
+            out.append(self.wgrad_stream)
+        return out
+
     def _join_wgrad(self):
         if self.wgrad_stream is not None and self._wgrad_pending:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
@@ -473,7 +480,6 @@ class TrainEngine:
                                    t_drop=(self._sites(side, n - 1)["res_f"], r_res))
             dparts = None
         if self.grad_ready is not None:
-            self._join_wgrad()
             self.grad_ready(first_ready)
         for li in range(n - 1, -1, -1):
             L, r = layers[li], saved["layers"][li]
@@ -538,7 +544,6 @@ class TrainEngine:
             else:                # a = x: d x = dy + da, folded into the next LayerNorm backward
                 dparts = da
             if self.grad_ready is not None:
-                self._join_wgrad()
                 self.grad_ready(self._bucket_of[p])
         return dy, dparts
 
