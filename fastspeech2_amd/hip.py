@@ -109,7 +109,17 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+try:                                   # fast path: two C calls instead of torch.cuda.current_stream()'s Python layers,
+    _raw_stream = torch._C._cuda_getCurrentRawStream      # which cost ~40 % of the host time of a batch-1 forward
+    _cur_device = torch._C._cuda_getDevice
+except AttributeError:                 # pragma: no cover - other torch builds
+    _raw_stream = _cur_device = None
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device"""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(_cur_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
