@@ -45,7 +45,8 @@ struct ConvGemmArgs {
     int M, N, Cin, taps;
     int ldx, ldr, ldo;
     int relu, out_f32;        // relu: activation code 0 none / 1 ReLU / 2 tanh
-    int n_tiles;
+    int n_tiles, m_tiles;
+    int xcd_sets, xcd_group;  // XCD-aware tile order: 8 / xcd_sets XCDs share a group of xcd_group N tiles (0: plain order)
     int ksplit;               // split of the channel-chunk range over gridDim.y partial outputs
     long long split_stride;   // elements between two partial outputs
 };
@@ -93,10 +94,22 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, i = lane & 15;
 
-    // blocks that share W columns have equal blockIdx % n_tiles -> same XCD L2 under round-robin
-    // dispatch when n_tiles divides 8 or is a multiple of it (speed only)
-    const int n_tile = blockIdx.x % a.n_tiles;
-    const int m_tile = blockIdx.x / a.n_tiles;
+    // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own 4 MB L2).  Plain order: blocks that
+    // share W columns have equal blockIdx % n_tiles -> same XCD when n_tiles divides 8, but then every XCD fetches
+    // every X tile.  XCD-aware order (xcd_sets > 0): XCD x works on the N-tile group x % sets (its W slices stay
+    // in that L2) and, inside the group, walks the M tiles m = (slot / group) * (8 / sets) + x / sets: an X tile is
+    // fetched by `sets` XCDs instead of by all of them.  (speed only; every (m, n) tile is visited exactly once)
+    int n_tile, m_tile;
+    if (a.xcd_sets > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int set = xcd % a.xcd_sets, member = xcd / a.xcd_sets;
+        n_tile = set * a.xcd_group + slot % a.xcd_group;
+        m_tile = (slot / a.xcd_group) * (8 / a.xcd_sets) + member;
+        if (m_tile >= a.m_tiles) return;
+    } else {
+        n_tile = blockIdx.x % a.n_tiles;
+        m_tile = blockIdx.x / a.n_tiles;
+    }
     const int m0 = m_tile * BM;
     const int n0 = n_tile * BN;
     const int pad = (a.taps - 1) >> 1;
@@ -447,7 +460,27 @@ static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     }
     a.n_tiles = (a.N + BN - 1) / BN;
     const int m_tiles = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC>), dim3(a.n_tiles * m_tiles, a.ksplit),
+    a.m_tiles = m_tiles;
+    int grid_x = a.n_tiles * m_tiles;
+    a.xcd_sets = a.xcd_group = 0;
+    {
+        // N tiles whose W slices (all taps) fit ~2.5 MB of an XCD's L2 form a group; sets = n_tiles / group
+        static const int xcd_off = getenv("FS2_CONV_XCD") ? atoi(getenv("FS2_CONV_XCD")) : 1;
+        const double slice = (double)a.taps * BN * a.Cin * sizeof(T);     // all K ranges of a split are resident together
+        int group = (int)(2.5e6 / slice);
+        if (xcd_off && group >= 2 && a.n_tiles >= 2 && m_tiles >= 64) {
+            group = group > a.n_tiles ? a.n_tiles : group;
+            while (group > 1 && (a.n_tiles % group != 0 || (a.n_tiles / group) > 8 || 8 % (a.n_tiles / group) != 0)) --group;
+            const int sets = a.n_tiles / group;
+            if (group >= 2 && sets >= 1 && sets <= 8 && 8 % sets == 0) {
+                a.xcd_sets = sets;
+                a.xcd_group = group;
+                const int per = 8 / sets;
+                grid_x = 8 * group * ((m_tiles + per - 1) / per);
+            }
+        }
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC>), dim3(grid_x, a.ksplit),
                        dim3(128 * WM), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_conv_gemm");
     return FS2_OK;
