@@ -68,7 +68,7 @@ EXPORTS = sorted(list(_SIGNATURES) + list(_SIZE_QUERIES) + ["fs2_last_error", "f
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    return os.environ.get("FS2_LIB") or _build.LIB_PATH      # FS2_LIB: an alternative build (kernel experiments)
 
 
 def load():
