@@ -157,7 +157,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_ffn_conv_traffic.json")
         if args.dtype == "bf16" and os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = dict(bound="mfma", kernel="fs2::conv_gemm_kernel<%s> (FFN conv k=9, both convs)" % args.dtype,
+        roofline = dict(bound="mfma", kernel="fs2::conv_gemm_kernel<%s, ..., KT=9> (the k=9 FFN convs, own kernel symbol; "
+                                                "timed one forward at a time, i.e. without the cross-batch overlap of "
+                                                "the throughput loop)" % args.dtype,
                         achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                         traffic=traffic, launches=n, avg_launch_us=round(t_ms * 1e3 / n, 2),
                         flops_per_launch=fl / n)

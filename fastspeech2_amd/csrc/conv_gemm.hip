@@ -69,8 +69,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 // Workgroup = 2 WM waves laid out WM (tokens) x 2 (channels); wave tile 16 MT x 16 NT; block tile
 // (16 MT WM) x (32 NT).  XDB: X image double-buffered (refill overlapped) or single (less LDS).
 // OCC: workgroups per CU the register allocation is tuned for.
-template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC>
+// KT: number of taps at compile time (9: the FFN convs get their own kernel symbol, so profiler summaries list
+// them apart from the k = 1 / 3 / 5 GEMMs, and their tap loop bounds are constants), 0: run-time a.taps.
+template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0>
 __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_kernel(ConvGemmArgs a) {
+    const int taps = KT ? KT : a.taps;
     constexpr bool DMA = MODE != 0;
     constexpr int NW = 2 * WM;
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
@@ -112,13 +115,13 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     }
     const int m0 = m_tile * BM;
     const int n0 = n_tile * BN;
-    const int pad = (a.taps - 1) >> 1;
+    const int pad = (taps - 1) >> 1;
     // split-K: workgroup y handles channel chunks [chunk_lo, chunk_hi) and writes partial output y
     const int nchunks_all = (a.Cin + BKE - 1) / BKE;
     const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
     const int chunk_lo = blockIdx.y * cps;
     const int chunk_hi = min(nchunks_all, chunk_lo + cps);
-    const int nsteps = max(chunk_hi - chunk_lo, 0) * a.taps;
+    const int nsteps = max(chunk_hi - chunk_lo, 0) * taps;
     const float* bias = blockIdx.y == 0 ? a.bias : nullptr;
 
     const T* __restrict__ X = (const T*)a.X;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             stage_x(chunk_lo, 0);
             stage_w(0, chunk_lo, 0);
             if (nsteps > 1) {
-                const bool wrap = a.taps == 1;
+                const bool wrap = taps == 1;
                 stage_w(wrap ? 0 : 1, wrap ? chunk_lo + 1 : chunk_lo, 1);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");   // X + W(0) landed; W(1) in flight
             } else {
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
         }
         __builtin_amdgcn_s_barrier();
         int tap = 0, chunk = chunk_lo;             // of step s
-        int tap2 = 2 % a.taps, chunk2 = chunk_lo + 2 / a.taps;   // of step s + 2
+        int tap2 = 2 % taps, chunk2 = chunk_lo + 2 / taps;   // of step s + 2
         int ring = 0;
         for (int s = 0; s < nsteps; ++s) {
             const bool issue = (s + 2) < nsteps;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                 // barrier that ended it
                 if (issue) stage_w(tap2, chunk2, ring2);
             });
-            const bool last_tap = (tap + 1) == a.taps;
+            const bool last_tap = (tap + 1) == taps;
             // W(s+1) (issued during step s-1) must have landed; the WP pieces of W(s+2) may stay in flight
             if (issue)
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WP) : "memory");
@@ -284,8 +287,8 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
             ring = ring == 2 ? 0 : ring + 1;
-            if (++tap == a.taps) { tap = 0; ++chunk; }
-            if (++tap2 == a.taps) { tap2 = 0; ++chunk2; }
+            if (++tap == taps) { tap = 0; ++chunk; }
+            if (++tap2 == taps) { tap2 = 0; ++chunk2; }
         }
     } else {
         if (nsteps > 0) {
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
         int tap = 0, chunk = chunk_lo;
         for (int step = 0; step < nsteps; ++step) {
             int ntap = tap + 1, nchunk = chunk;
-            if (ntap == a.taps) { ntap = 0; nchunk = chunk + 1; }
+            if (ntap == taps) { ntap = 0; nchunk = chunk + 1; }
             const bool has_next = (step + 1) < nsteps;
             const bool next_x = has_next && (ntap == 0);
             if (DMA) {   // LDS-DMA prefetch of step+1 into the other W buffer, in flight during the MFMAs
@@ -448,13 +451,13 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     }
 }
 
-template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC>
+template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
     constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + (MODE == 2 ? 3 : 2) * BN * CG_ROWB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC>,
+        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -480,7 +483,7 @@ static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
             }
         }
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC>), dim3(grid_x, a.ksplit),
+    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>), dim3(grid_x, a.ksplit),
                        dim3(128 * WM), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_conv_gemm");
     return FS2_OK;
@@ -505,6 +508,10 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
     int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
     if (forced) best = forced;
+    if (a.taps == 9) {      // the FFN convs: own symbol, compile-time tap count
+        if (best == 3) return launch_conv_gemm<T, 3, 4, 2, 1, false, 3, 9>(a, stream);
+        if (best == 4) return launch_conv_gemm<T, 4, 4, 2, 1, false, 3, 9>(a, stream);
+    }
     if (best == 3) return launch_conv_gemm<T, 3, 4, 2, 1, false, 3>(a, stream);
     if (best == 2) return launch_conv_gemm<T, 2, 4, 2, 1, false, 3>(a, stream);
     return launch_conv_gemm<T, 4, 4, 2, 1, false, 3>(a, stream);
