@@ -165,6 +165,8 @@ class Engine:
         if self._pe is None or self._pe.shape[0] < T:
             n = max(T, 1024)
             n = 1 << (n - 1).bit_length()
+            if self._pe is not None:          # other streams may still read the smaller table: keep it alive
+                self._pe_retired = getattr(self, "_pe_retired", []) + [self._pe]
             self._pe = posenc_table(n, self.d).to(self.dev)
         return self._pe
 
