@@ -64,8 +64,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 
 // MODE 0: generic register staging (any Cin % 8 == 0), X/W double-buffered, synchronous
 // MODE 1: LDS-DMA, X single + W double buffer, one __syncthreads per step (3 workgroups / CU)
-// MODE 2: LDS-DMA, X single + 3-stage W ring: the DMA of step s+2 is issued in the middle of step s
-//         and stays in flight across the end-of-step barrier (counted vmcnt + raw s_barrier)
 // Workgroup = 2 WM waves laid out WM (tokens) x 2 (channels); wave tile 16 MT x 16 NT; block tile
 // (16 MT WM) x (32 NT).  XDB: X image double-buffered (refill overlapped) or single (less LDS).
 // OCC: workgroups per CU the register allocation is tuned for.
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [X buf0]([X buf1])[W stage 0][W stage 1]([W stage 2])
+    // [X buf0]([X buf1])[W stage 0][W stage 1]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -249,48 +247,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
         }
     };
 
-    if constexpr (MODE == 2) {
-        static_assert(W_INSTR % NW == 0, "ring mode needs an equal number of W pieces per wave");
-        constexpr int WP = W_INSTR / NW;           // W DMA pieces per wave per step
-        // step s -> (chunk_lo + s / taps, s % taps); W(s) lives in ring stage s % 3
-        if (nsteps > 0) {
-            stage_x(chunk_lo, 0);
-            stage_w(0, chunk_lo, 0);
-            if (nsteps > 1) {
-                const bool wrap = taps == 1;
-                stage_w(wrap ? 0 : 1, wrap ? chunk_lo + 1 : chunk_lo, 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WP) : "memory");   // X + W(0) landed; W(1) in flight
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-        int tap = 0, chunk = chunk_lo;             // of step s
-        int tap2 = 2 % taps, chunk2 = chunk_lo + 2 / taps;   // of step s + 2
-        int ring = 0;
-        for (int s = 0; s < nsteps; ++s) {
-            const bool issue = (s + 2) < nsteps;
-            const int ring2 = ring >= 1 ? ring - 1 : 2;            // (s + 2) % 3
-            compute(tap, 0, ring, [&]() __attribute__((always_inline)) {
-                // ring stage (s+2)%3 == (s-1)%3 was last read in step s-1; every wave has passed the
-                // barrier that ended it
-                if (issue) stage_w(tap2, chunk2, ring2);
-            });
-            const bool last_tap = (tap + 1) == taps;
-            // W(s+1) (issued during step s-1) must have landed; the WP pieces of W(s+2) may stay in flight
-            if (issue)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WP) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (last_tap && (s + 1) < nsteps) {   // every wave is done with X(chunk): refill the single image
-                stage_x(chunk + 1, 0);
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            ring = ring == 2 ? 0 : ring + 1;
-            if (++tap == taps) { tap = 0; ++chunk; }
-            if (++tap2 == taps) { tap2 = 0; ++chunk2; }
-        }
-    } else {
+    {
         if (nsteps > 0) {
             stage_x(chunk_lo, 0);
             stage_w(0, chunk_lo, 0);
@@ -454,7 +411,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
 template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
-    constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + (MODE == 2 ? 3 : 2) * BN * CG_ROWB;
+    constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>,

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import hip
-from .engine import LN_EPS, posenc_table
+from .engine import LN_EPS, Engine, posenc_table
 from .hip import BF16, F32, call, ptr, stream
 
 
@@ -219,18 +219,7 @@ class TrainEngine:
         return torch.empty((max(int(nbytes), 16) + 3) // 4, device=self.dev, dtype=torch.float32)
 
     def _ksplit(self, M, N, Cin, taps):
-        nch = -(-Cin // (64 if self.code == BF16 else 32))
-        blocks = -(-M // 128) * -(-N // 128)
-        if 200 <= blocks < 600 and nch * taps >= 64:
-            # narrow output, long K (second FFN conv at frame level): ~400 workgroups leave the CUs with one or two
-            # resident each; three K ranges (~1200 workgroups, 3 per CU) measured 82 vs 89 us per launch
-            return 3
-        if blocks >= 200 or nch * taps < 32:
-            return 1
-        ks = max(1, min(nch, 8, 256 // blocks))
-        while ks > 1 and (nch // ks) * taps < 8:
-            ks -= 1
-        return ks
+        return Engine._ksplit(M, N, Cin, taps, self.code)       # same split-K rule as the inference schedule
 
     def _rate(self, key):
         return float(self.rates.get(key, 0.0)) if self.drop_on else 0.0
