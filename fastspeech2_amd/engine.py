@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .trace import span
 from .hip import F32, BF16, call, ptr, stream
 
 LN_EPS = 1e-12  # network/utils.py:41
@@ -294,8 +295,10 @@ class Engine:
         overrides (teacher forcing): durations int32 [Mp], pitch fp32 [Mf,4], energy fp32 [Mf,1].
         Returns packed outputs; `olens` is a host list (one device->host read of B+1 integers is the
         only synchronisation of the forward)."""
-        ctx = self.phone_phase(ids, ilens, duration_control, ds, want_attention)
-        return self.frame_phase(ctx, ps, es, pitch_control, energy_control)
+        with span("fs2.phone_phase"):
+            ctx = self.phone_phase(ids, ilens, duration_control, ds, want_attention)
+        with span("fs2.frame_phase"):
+            return self.frame_phase(ctx, ps, es, pitch_control, energy_control)
 
     def phone_phase(self, ids, ilens, duration_control=1.0, ds=None, want_attention=False) -> Dict[str, object]:
         """Phone-level half: embedding, encoder stack, duration predictor, LengthRegulator planning.

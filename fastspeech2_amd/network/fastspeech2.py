@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .. import synth
 from .loss import DurationPredictorLoss
+from ..trace import span
 from .utils import Reporter, initialize, make_non_pad_mask
 
 LN_EPS = 1e-12  # network/utils.py:41
@@ -118,7 +119,8 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, eng, batch, names, *params):
         ids, il, ol, ds_p, ps_p, es_p, ys_p = batch
-        outs, saved = eng.forward(ids, il, ol, ds_p, ps_p, es_p, ys_p)
+        with span("fs2.train_forward"):
+            outs, saved = eng.forward(ids, il, ol, ds_p, ps_p, es_p, ys_p)
         l1_loss = F.l1_loss(outs["before"], ys_p)                              # network/fastspeech2.py:271-274
         duration_loss = model.duration_criterion(outs["log_durations"], ds_p)  # network/loss.py:5-14
         pitch_loss = model.mse_criterion(outs["pitch"], ps_p)
@@ -145,7 +147,8 @@ class _TrainStep(torch.autograd.Function):
         held = [(n, p) for n, p in params if p.grad is not None]
         aliased = any(p.grad.data_ptr() == eng.G[n].data_ptr() for n, p in held)
         keep = eng.flat.clone() if aliased else None
-        G = eng.backward(ctx.saved, up)
+        with span("fs2.train_backward"):
+            G = eng.backward(ctx.saved, up)
         ctx.saved = None
         if keep is not None:
             eng.flat.add_(keep)
