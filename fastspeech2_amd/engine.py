@@ -9,7 +9,7 @@ Schedule follows network/fastspeech2.py:187-230 (`_forward`), network/encoder.py
 and network/variance_adaptor.py:178-207 with the repair set of SURVEY.md §0.1.
 """
 import math
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch

@@ -77,7 +77,6 @@ class TrainEngine:
             if p.device != self.dev or p.dtype != torch.float32 or not p.is_contiguous():
                 raise hip.HipError("parameter %s must be a contiguous fp32 tensor on %s" % (k, self.dev))
         self.scaled = cfg["use_scaled_pos_enc"]
-        self.ff_conv = cfg["positionwise_layer_type"] == "conv1d"
         self.odim = cfg["odim"]
         self.idim = cfg["idim"]
         self.odim_pad = -(-self.odim // self.epv) * self.epv

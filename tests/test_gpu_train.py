@@ -4,7 +4,6 @@ import numpy as np
 import pytest
 import torch
 
-from fastspeech2_amd import synth
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer
 from oracle import fs2_oracle
 from tests import helpers

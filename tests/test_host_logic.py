@@ -4,7 +4,6 @@ and that the product path refuses to run without the HIP device instead of falli
 import os
 import re
 
-import numpy as np
 import pytest
 import torch
 

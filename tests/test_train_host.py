@@ -1,7 +1,6 @@
 """CPU checks of the training plumbing: Noam schedule (vs the reference's own class when it is
 importable), the update rule of CustomUpdater.update_core, and the bucketed data-parallel gradient
 averaging on 2 gloo ranks (the N > 1 training path)."""
-import math
 import os
 import socket
 
