@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="no cross-step overlap: one forward after the other")
     ap.add_argument("--frame-streams", type=int, default=2, help="alternate the frame-level halves over this many streams")
     ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with one GPU: still create the nccl (RCCL) group and run the barrier / reductions")
     return ap.parse_args()
 
 
@@ -92,9 +94,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29572")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     model, sd_np, kw = build_model(args.dtype, args.encoder_dtype, dev)
     eng = model.engine()
