@@ -36,8 +36,9 @@ __global__ void build_seg_kernel(const int* __restrict__ cu, int B, int2* __rest
 template <typename T>
 __global__ void embed_posenc_kernel(const long long* __restrict__ ids, const int* __restrict__ pos,
                                     const float* __restrict__ emb, const float* __restrict__ pe,
-                                    float xscale, float alpha, float* __restrict__ out_f32,
-                                    T* __restrict__ out_t, int M, int d, int idim) {
+                                    float xscale, float alpha, const float* __restrict__ alpha_dev,
+                                    float* __restrict__ out_f32, T* __restrict__ out_t, int M, int d, int idim) {
+    if (alpha_dev) alpha = *alpha_dev;       // training: the learnable scale is read on the device (no host sync)
     const int dv = d >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * dv) return;
@@ -282,8 +283,10 @@ __global__ void variance_add_posenc_kernel(const float* __restrict__ hs, const f
                                            const float* __restrict__ bp, const float* __restrict__ We,
                                            const float* __restrict__ be, float pscale, float escale,
                                            const float* __restrict__ pe, const int* __restrict__ pos, float xscale,
-                                           float alpha, float* __restrict__ hs_va, float* __restrict__ out_f32,
+                                           float alpha, const float* __restrict__ alpha_dev,
+                                           float* __restrict__ hs_va, float* __restrict__ out_f32,
                                            T* __restrict__ out_t, int M, int d, int pdim, int edim) {
+    if (alpha_dev) alpha = *alpha_dev;
     const int dv = d >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * dv) return;
@@ -394,21 +397,35 @@ extern "C" int fs2_build_seg(const int* cu, int B, int* seg, int* pos, int M, hi
     return FS2_OK;
 }
 
-extern "C" int fs2_embed_posenc(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
-                                float alpha, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
-                                hipStream_t stream) {
+static int embed_posenc_entry(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
+                              float alpha, const float* alpha_dev, float* out_f32, void* out_t, int M, int d, int idim,
+                              int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(ids && pos && emb && pe && (out_f32 || out_t), "fs2_embed_posenc: null pointer");
     FS2_CHECK_ARG(d > 0 && d % 4 == 0 && idim > 0 && M >= 0, "fs2_embed_posenc: d=%d must be a multiple of 4", d);
     if (M == 0) return FS2_OK;
     const long long n = (long long)M * (d / 4);
     if (dtype == 1)
         hipLaunchKernelGGL(embed_posenc_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, ids, pos, emb, pe,
-                           xscale, alpha, out_f32, (bf16_t*)out_t, M, d, idim);
+                           xscale, alpha, alpha_dev, out_f32, (bf16_t*)out_t, M, d, idim);
     else
         hipLaunchKernelGGL(embed_posenc_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, ids, pos, emb, pe,
-                           xscale, alpha, out_f32, (float*)out_t, M, d, idim);
+                           xscale, alpha, alpha_dev, out_f32, (float*)out_t, M, d, idim);
     FS2_CHECK_LAUNCH("fs2_embed_posenc");
     return FS2_OK;
+}
+
+extern "C" int fs2_embed_posenc(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
+                                float alpha, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
+                                hipStream_t stream) {
+    return embed_posenc_entry(ids, pos, emb, pe, xscale, alpha, nullptr, out_f32, out_t, M, d, idim, dtype, stream);
+}
+
+// as fs2_embed_posenc with alpha read from device memory (the nn.Parameter of ScaledPositionalEncoding)
+extern "C" int fs2_embed_posenc_dev(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
+                                    const float* alpha_dev, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
+                                    hipStream_t stream) {
+    FS2_CHECK_ARG(alpha_dev, "fs2_embed_posenc_dev: null alpha");
+    return embed_posenc_entry(ids, pos, emb, pe, xscale, 1.0f, alpha_dev, out_f32, out_t, M, d, idim, dtype, stream);
 }
 
 static int add_layernorm_entry(const float* x, const float* parts, int nparts, long long part_stride, const float* w,
@@ -514,11 +531,11 @@ extern "C" int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phon
     return FS2_OK;
 }
 
-extern "C" int fs2_variance_add_posenc(const float* hs, const float* pitch, const float* energy, const float* Wp,
-                                       const float* bp, const float* We, const float* be, float pscale, float escale,
-                                       const float* pe, const int* pos, float xscale, float alpha, float* hs_va,
-                                       float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
-                                       hipStream_t stream) {
+static int variance_add_entry(const float* hs, const float* pitch, const float* energy, const float* Wp,
+                              const float* bp, const float* We, const float* be, float pscale, float escale,
+                              const float* pe, const int* pos, float xscale, float alpha, const float* alpha_dev,
+                              float* hs_va, float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
+                              hipStream_t stream) {
     FS2_CHECK_ARG(hs && pitch && energy && Wp && bp && We && be && pe && pos && (out_f32 || out_t),
                   "fs2_variance_add_posenc: null pointer");
     FS2_CHECK_ARG(d > 0 && d % 4 == 0 && pdim >= 1 && edim >= 1, "fs2_variance_add_posenc: bad dims");
@@ -526,14 +543,34 @@ extern "C" int fs2_variance_add_posenc(const float* hs, const float* pitch, cons
     const long long n = (long long)M * (d / 4);
     if (dtype == 1)
         hipLaunchKernelGGL(variance_add_posenc_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
-                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, hs_va, out_f32,
+                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, alpha_dev, hs_va, out_f32,
                            (bf16_t*)out_t, M, d, pdim, edim);
     else
         hipLaunchKernelGGL(variance_add_posenc_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
-                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, hs_va, out_f32,
+                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, alpha_dev, hs_va, out_f32,
                            (float*)out_t, M, d, pdim, edim);
     FS2_CHECK_LAUNCH("fs2_variance_add_posenc");
     return FS2_OK;
+}
+
+extern "C" int fs2_variance_add_posenc(const float* hs, const float* pitch, const float* energy, const float* Wp,
+                                       const float* bp, const float* We, const float* be, float pscale, float escale,
+                                       const float* pe, const int* pos, float xscale, float alpha, float* hs_va,
+                                       float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
+                                       hipStream_t stream) {
+    return variance_add_entry(hs, pitch, energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, nullptr, hs_va,
+                              out_f32, out_t, M, d, pdim, edim, dtype, stream);
+}
+
+// as fs2_variance_add_posenc with the decoder's alpha read from device memory
+extern "C" int fs2_variance_add_posenc_dev(const float* hs, const float* pitch, const float* energy, const float* Wp,
+                                           const float* bp, const float* We, const float* be, float pscale, float escale,
+                                           const float* pe, const int* pos, float xscale, const float* alpha_dev,
+                                           float* hs_va, float* out_f32, void* out_t, int M, int d, int pdim, int edim,
+                                           int dtype, hipStream_t stream) {
+    FS2_CHECK_ARG(alpha_dev, "fs2_variance_add_posenc_dev: null alpha");
+    return variance_add_entry(hs, pitch, energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, 1.0f, alpha_dev, hs_va,
+                              out_f32, out_t, M, d, pdim, edim, dtype, stream);
 }
 
 extern "C" int fs2_unpack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C,

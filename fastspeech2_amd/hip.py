@@ -27,6 +27,9 @@ _P, _I, _F, _L, _U = c_void_p, c_int, c_float, c_longlong, c_uint
 _SIGNATURES = {
     "fs2_build_seg": [_P, _I, _P, _P, _I, _P],
     "fs2_embed_posenc": [_P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_embed_posenc_dev": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_variance_add_posenc_dev": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _F, _P, _P, _P, _P,
+                                    _I, _I, _I, _I, _I, _P],
     "fs2_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_conv_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "fs2_add_layernorm": [_P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],

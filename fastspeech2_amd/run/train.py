@@ -63,9 +63,18 @@ class GradReducer:
 
 class Updater:
     """update_core of run/train_decode.py:82-110: forward, loss / accum_grad, backward; every accum_grad
-    calls: clip_grad_norm_, skip the update when the norm is NaN, optimizer.step(), zero_grad()."""
+    calls: clip_grad_norm_, skip the update when the norm is NaN, optimizer.step(), zero_grad().
 
-    def __init__(self, model, grad_clip, optimizer, device=None, accum_grad=1, reducer: Optional[GradReducer] = None):
+    The reference reads the norm on the host (`math.isnan(grad_norm)`), which drains the GPU once per step.
+    With a fused torch Adam on the device (what `get_std_opt` builds) the same rule runs without that read: the
+    NaN flag stays a device scalar and is handed to the optimiser as `found_inf` (the GradScaler hook of fused
+    Adam: parameters, moments and step counts are left untouched when it is set).  The flag reaches the host
+    later through a pinned copy; a skipped step then takes back the schedule tick `NoamOpt.step()` had counted,
+    so the learning rates that follow are the reference's (in between, at most two updates see a rate one tick
+    ahead).  `sync_nan_check=True` restores the literal host-side check."""
+
+    def __init__(self, model, grad_clip, optimizer, device=None, accum_grad=1, reducer: Optional[GradReducer] = None,
+                 sync_nan_check: bool = False):
         self.model = model
         self.grad_clip = grad_clip
         self.optimizer = optimizer
@@ -75,9 +84,30 @@ class Updater:
         self.iteration = 0
         self.reducer = reducer
         self.last_grad_norm = None
+        self.sync_nan_check = sync_nan_check
+        self.skipped_steps = 0
+        self._pending = []           # (event, pinned flag) of updates whose NaN flag has not been read yet
+
+    def _base_optimizer(self):
+        return getattr(self.optimizer, "optimizer", self.optimizer)
+
+    def _resolve_pending(self, wait: bool = False):
+        keep = []
+        for ev, flag in self._pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                if float(flag) != 0.0:
+                    self.skipped_steps += 1
+                    logging.warning("grad norm is nan. Do not update model")
+                    if hasattr(self.optimizer, "_step"):
+                        self.optimizer._step -= 1      # NoamOpt.step() was not called by the reference
+            else:
+                keep.append((ev, flag))
+        self._pending = keep
 
     def update_core(self, batch: Dict[str, torch.Tensor]):
-        x = {k: (v.to(self.device) if self.device is not None else v) for k, v in batch.items()}
+        x = {k: (v.to(self.device) if (self.device is not None and hasattr(v, "to")) else v) for k, v in batch.items()}
         loss = self.model(**x).mean() / self.accum_grad
         loss.backward()
         self.forward_count += 1
@@ -86,14 +116,35 @@ class Updater:
         self.forward_count = 0
         grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
         self.last_grad_norm = grad_norm
-        logging.debug("grad norm=%s", grad_norm)
-        if math.isnan(float(grad_norm)):
-            logging.warning("grad norm is nan. Do not update model")
+        base = self._base_optimizer()
+        on_device = isinstance(grad_norm, torch.Tensor) and grad_norm.is_cuda and bool(base.defaults.get("fused"))
+        if on_device and not self.sync_nan_check:
+            self._resolve_pending()
+            found = torch.isnan(grad_norm).to(torch.float32).reshape(())
+            base.grad_scale, base.found_inf = None, found
+            try:
+                self.optimizer.step()                  # a no-op on the device when `found` is set
+            finally:
+                base.found_inf = None
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            host.copy_(found, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((ev, host))
         else:
-            self.optimizer.step()
+            logging.debug("grad norm=%s", grad_norm)
+            if math.isnan(float(grad_norm)):
+                self.skipped_steps += 1
+                logging.warning("grad norm is nan. Do not update model")
+            else:
+                self.optimizer.step()
         self.optimizer.zero_grad()
 
     def update(self, batch):
         self.update_core(batch)
         if self.forward_count == 0:
             self.iteration += 1
+
+    def finalize(self):
+        """read the outstanding NaN flags (end of training / before a snapshot)"""
+        self._resolve_pending(wait=True)

@@ -603,18 +603,16 @@ class TrainEngine:
         pos_p = self._empty((Mp,), torch.int32)
         call("fs2_build_seg", ptr(cu_phone), B, ptr(seg_p), ptr(pos_p), Mp, stream())
         pe = self._pe_table(max_il)
-        if self.scaled:
-            a_enc, a_dec = P["encoder.embed.1.alpha"], P["decoder.embed.0.alpha"]
-            enc_alpha, dec_alpha = float(a_enc), float(a_dec)      # host read of two scalars (once per step)
-            xscale = 1.0
-        else:
-            enc_alpha = dec_alpha = 1.0
-            xscale = math.sqrt(d)
+        xscale = 1.0 if self.scaled else math.sqrt(d)
         enc_pre, dec_pre = cfg["encoder_normalized_before"], cfg["decoder_normalized_before"]
         x32 = self._empty((Mp, d), torch.float32)
         xt = self._empty((Mp, d)) if (not enc_pre and self.code != F32) else None
-        call("fs2_embed_posenc", ptr(ids), ptr(pos_p), ptr(P["encoder.embed.0.weight"]), ptr(pe), xscale, enc_alpha,
-             ptr(x32), ptr(xt), Mp, d, self.idim, self.code, stream())
+        if self.scaled:        # alpha is a learnable parameter: read on the device, no host sync in the step
+            call("fs2_embed_posenc_dev", ptr(ids), ptr(pos_p), ptr(P["encoder.embed.0.weight"]), ptr(pe), xscale,
+                 ptr(P["encoder.embed.1.alpha"]), ptr(x32), ptr(xt), Mp, d, self.idim, self.code, stream())
+        else:
+            call("fs2_embed_posenc", ptr(ids), ptr(pos_p), ptr(P["encoder.embed.0.weight"]), ptr(pe), xscale, 1.0,
+                 ptr(x32), ptr(xt), Mp, d, self.idim, self.code, stream())
         if self._rate("enc_pos") > 0.0:
             call("fs2_dropout", ptr(x32), ptr(xt), Mp, d, self.seed, self.SITE_ENC_POS, self._rate("enc_pos"), self.code,
                  stream())
@@ -650,10 +648,14 @@ class TrainEngine:
         pe_f = self._pe_table(max_ol)
         y32 = self._empty((Mf, d), torch.float32)
         yt = self._empty((Mf, d)) if (not dec_pre and self.code != F32) else None
-        call("fs2_variance_add_posenc", ptr(hs_lr32), ptr(ps), ptr(es), ptr(P[va + "pitch_embed.conv.conv.weight"]),
-             ptr(P[va + "pitch_embed.conv.conv.bias"]), ptr(P[va + "energy_embed.conv.conv.weight"]),
-             ptr(P[va + "energy_embed.conv.conv.bias"]), 1.0, 1.0, ptr(pe_f), ptr(pos_f), xscale, dec_alpha, None,
-             ptr(y32), ptr(yt), Mf, d, self.pdim, self.edim, self.code, stream())
+        vargs = (ptr(hs_lr32), ptr(ps), ptr(es), ptr(P[va + "pitch_embed.conv.conv.weight"]),
+                 ptr(P[va + "pitch_embed.conv.conv.bias"]), ptr(P[va + "energy_embed.conv.conv.weight"]),
+                 ptr(P[va + "energy_embed.conv.conv.bias"]), 1.0, 1.0, ptr(pe_f), ptr(pos_f), xscale)
+        vtail = (None, ptr(y32), ptr(yt), Mf, d, self.pdim, self.edim, self.code, stream())
+        if self.scaled:
+            call("fs2_variance_add_posenc_dev", *vargs, ptr(P["decoder.embed.0.alpha"]), *vtail)
+        else:
+            call("fs2_variance_add_posenc", *vargs, 1.0, *vtail)
         if self._rate("dec_pos") > 0.0:
             call("fs2_dropout", ptr(y32), ptr(yt), Mf, d, self.seed, self.SITE_DEC_POS, self._rate("dec_pos"), self.code,
                  stream())

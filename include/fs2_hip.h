@@ -49,6 +49,11 @@ int fs2_embed_posenc(const long long* ids, const int* pos, const float* emb, con
                      float alpha, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
                      hipStream_t stream);
 
+/* fs2_embed_posenc with alpha read from device memory (training: the learnable nn.Parameter, no host read). */
+int fs2_embed_posenc_dev(const long long* ids, const int* pos, const float* emb, const float* pe, float xscale,
+                         const float* alpha_dev, float* out_f32, void* out_t, int M, int d, int idim, int dtype,
+                         hipStream_t stream);
+
 /* LayerNorm over channels, eps as given (reference: 1e-12), network/utils.py:39-47.
  * x fp32 [M,C]; writes fp32 and/or T copies. C % 4 == 0, C <= 1024. */
 int fs2_layernorm(const float* x, const float* w, const float* b, float* out_f32, void* out_t, int M, int C,
@@ -117,6 +122,13 @@ int fs2_variance_add_posenc(const float* hs, const float* pitch, const float* en
                             const float* pe, const int* pos, float xscale, float alpha, float* hs_va,
                             float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
                             hipStream_t stream);
+
+/* fs2_variance_add_posenc with the decoder's alpha read from device memory (training). */
+int fs2_variance_add_posenc_dev(const float* hs, const float* pitch, const float* energy, const float* Wp,
+                                const float* bp, const float* We, const float* be, float pscale, float escale,
+                                const float* pe, const int* pos, float xscale, const float* alpha_dev, float* hs_va,
+                                float* out_f32, void* out_t, int M, int d, int pdim, int edim, int dtype,
+                                hipStream_t stream);
 
 /* packed [M,C] <-> zero-padded [B,Tmax,C] (pad_list, network/utils.py:50-56). */
 int fs2_unpack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C, hipStream_t stream);

@@ -181,3 +181,34 @@ def test_two_process_data_parallel_step(tmp_path):
             a = torch.from_numpy(got[r][k.replace(".", "__")]).double()
             assert (a - w).abs().max().item() <= 1e-6 * max(1.0, w.abs().max().item()), (k, r)
     assert got[0]["loss"] != got[1]["loss"]          # different shares of the data
+
+
+def test_async_nan_guard_skips_the_update_and_takes_back_the_schedule_tick():
+    from fastspeech2_amd.network.optimizer import get_std_opt
+    from fastspeech2_amd.run.train import Updater
+    _, meta = helpers.load_golden("train_tiny_linear")
+    model = _model(meta)
+    cfg = helpers.oracle_cfg(meta)
+    xs, il, ys, ol, ds, ps, es = _ragged_batch(cfg, 2, [12, 7])
+    good = dict(xs=xs, ilens=il, ys=ys, olens=ol, ds=ds, ps=ps, es=es)
+    bad = dict(good, ps=ps.clone())
+    bad["ps"][0, 0] = float("nan")                           # MSE target -> NaN gradient (an L1 target would give sign(NaN) = 0)
+    opt = get_std_opt(model, cfg["adim"], 20, 1.0)
+    up = Updater(model, grad_clip=1.0, optimizer=opt, device=DEV)
+    up.update(good)
+    up.finalize()
+    w0 = {k: p.detach().clone() for k, p in model.named_parameters()}
+    steps0 = [int(st["step"]) for st in opt.optimizer.state.values()]
+    up.update(bad)                                           # NaN gradient norm -> no update
+    up.finalize()
+    assert up.skipped_steps == 1 and opt._step == 1          # the tick counted by NoamOpt.step() was taken back
+    assert all(torch.equal(w0[k], p.detach()) for k, p in model.named_parameters())
+    assert [int(st["step"]) for st in opt.optimizer.state.values()] == steps0
+    up.update(good)
+    up.finalize()
+    assert opt._step == 2 and up.skipped_steps == 1
+    assert any(not torch.equal(w0[k], p.detach()) for k, p in model.named_parameters())
+    # literal host-side check gives the same decisions
+    up2 = Updater(model, grad_clip=1.0, optimizer=opt, device=DEV, sync_nan_check=True)
+    up2.update(bad)
+    assert up2.skipped_steps == 1 and opt._step == 2
