@@ -14,6 +14,10 @@
 // LDS rows are 256 bytes; their 16-byte slots are rotated by 2*row so that the 4x16 blocks of a
 // transposed read spread over the banks (the DMA applies the rotation on its per-lane SOURCE
 // address, as in attention.hip).
+// The per-token utterance bounds (seg) of a block travel with it through the same DMA (two 4-byte pieces), so
+// the loop holds no ordinary global load: hipcc drains every LDS-DMA in flight (vmcnt(0)) at the first use of
+// one.  Stages form a ring of NST buffers filled NST - 1 blocks ahead; a counted s_waitcnt vmcnt(N) and a raw
+// s_barrier retire exactly the block about to be read and leave the younger ones in flight.
 // Grid: x = (n tile, c tile, tap), y = split of the token range.  Every workgroup writes its fp32
 // partial tile; conv_wgrad_reduce sums the splits in a fixed order (deterministic, no atomics)
 // and emits the reference parameter layout (N, Cin, taps).
@@ -35,13 +39,71 @@ struct WgradArgs {
     int n_tiles, c_tiles, ksplit;
 };
 
+constexpr int wgrad_stages(int tw) { return tw == 3 ? 3 : 2; }     // ring depth (LDS: 3 x 33.5 KB, one workgroup / CU | 2 x 32.5 KB, two)
+
 typedef __attribute__((address_space(3))) void wg_lds_void;
 typedef const __attribute__((address_space(1))) void wg_gbl_void;
 
+template <int N>
+__device__ __forceinline__ void wg_wait_vm_barrier() {
+    // stage retired for this wave (at most N younger DMA instructions outstanding), then every wave's
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// LDS reads of the staged seg rows, as asm: behind an ordinary LDS load hipcc puts s_waitcnt vmcnt(0) while an
+// LDS-DMA is in flight (it cannot tell the images apart), which would serialise the ring.
+typedef int wg_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned wg_lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void wg_lds_read_first_last(const void* rows, int2& first, int& last_x) {
+    unsigned long long f;
+    int l;
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %2 offset:504\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(f), "=&v"(l) : "v"(wg_lds_addr(rows)) : "memory");
+    first.x = (int)(unsigned)f;
+    first.y = (int)(unsigned)(f >> 32);
+    last_x = l;
+}
+// rows r..r+3 and r+16..r+19 of the seg image (8 x int2)
+__device__ __forceinline__ void wg_lds_read_rows8(const void* row_r, int2 (&out)[8]) {
+    wg_i4 q0, q1, q2, q3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\t"
+                 "ds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(wg_lds_addr(row_r)) : "memory");
+    out[0] = make_int2(q0[0], q0[1]); out[1] = make_int2(q0[2], q0[3]);
+    out[2] = make_int2(q1[0], q1[1]); out[3] = make_int2(q1[2], q1[3]);
+    out[4] = make_int2(q2[0], q2[1]); out[5] = make_int2(q2[2], q2[3]);
+    out[6] = make_int2(q3[0], q3[1]); out[7] = make_int2(q3[2], q3[3]);
+}
+
+// The 16 transposed reads of one fragment step (8 fragments: tokens +0..15 and +16..31 each), for the same reason.
+typedef unsigned wg_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+#define WG_TR2(o0, o1, a) "ds_read_b64_tr_b16 %" #o0 ", %" #a " offset:%24\n\tds_read_b64_tr_b16 %" #o1 ", %" #a " offset:%25\n\t"
+template <int OFF>
+__device__ __forceinline__ void wg_tr_read16(const unsigned (&ad)[8], bf16x8 (&out)[8]) {
+    wg_u2 r[16];
+    asm volatile(WG_TR2(0, 1, 16) WG_TR2(2, 3, 17) WG_TR2(4, 5, 18) WG_TR2(6, 7, 19) WG_TR2(8, 9, 20) WG_TR2(10, 11, 21)
+                     WG_TR2(12, 13, 22) WG_TR2(14, 15, 23) "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+                   "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "n"(OFF),
+                   "n"(OFF + 16 * WG_ROWB)
+                 : "memory");
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const wg_u4 v = {r[2 * k][0], r[2 * k][1], r[2 * k + 1][0], r[2 * k + 1][1]};
+        out[k] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+#undef WG_TR2
+
 // TW = taps per workgroup: 4 TW waves; wave (wt, wn, wc) owns the 64 x 64 quadrant (wn, wc) of tap (group * TW + wt).
 // The dY block and ONE X block with TW - 1 extra rows serve all TW taps (shifted row views), which cuts the
-// operand traffic per MFMA by TW.  TW = 3 for 3 | taps (12 waves, one workgroup per CU), else 1 (two per CU).
-template <typename T, int TW>
+// operand traffic per MFMA by TW.  TW = 3 for 3 | taps (12 waves, one workgroup per CU, ring of 3 stages), else 1
+// (4 waves, two workgroups per CU, 2 stages).  SEG: taps > 1 (utterance bounds staged with every block).
+template <typename T, int TW, bool SEG>
 __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(WgradArgs a) {
     typedef typename Frag<T>::type frag_t;
     constexpr int EPS = 16 / (int)sizeof(T);              // elements per 16-byte slot
@@ -49,11 +111,16 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
     constexpr int WT = BCH / 32;                          // 16-channel tiles per wave per side: 4 / 2
     constexpr int PIECES = WG_TILE_BYTES / 1024;          // 16 DMA pieces (4 rows each) of the dY tile
     constexpr int XPIECES = (WG_KT + TW - 1 + 3) / 4;     // X tile: 64 + TW - 1 rows
-    constexpr int STAGE_BYTES = (PIECES + XPIECES) * 1024;
+    constexpr int SEGOFF = (PIECES + XPIECES) * 1024;     // 64 int2 behind the two images
+    constexpr int STAGE_BYTES = SEGOFF + (SEG ? 512 : 0);
+    constexpr int TOT = PIECES + XPIECES + (SEG ? 2 : 0); // DMA instructions per stage
     constexpr int NWAVES = 4 * TW;
+    constexpr int PW = (TOT + NWAVES - 1) / NWAVES;       // per wave (the last ones repeat a piece: equal counts)
+    constexpr int NST = wgrad_stages(TW);
+    constexpr int AHEAD = NST - 1;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // stage s: dY image at smem + s * STAGE_BYTES, X image right behind it
+    // stage s: dY image at smem + s * STAGE_BYTES, X image right behind it, then the seg rows
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,59 +143,71 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
 
     const T* __restrict__ dY = (const T*)a.dY;
     const T* __restrict__ X = (const T*)a.X;
+    const int* __restrict__ segw = (const int*)a.seg;
 
     auto stage = [&](int kb, int st) __attribute__((always_inline)) {
         unsigned char* ydst = smem + st * STAGE_BYTES;
         unsigned char* xdst = ydst + WG_TILE_BYTES;
         const int mb = kb * WG_KT;
-        for (int p = wave; p < PIECES + XPIECES; p += NWAVES) {
-            const bool isx = p >= PIECES;
-            const int q = isx ? p - PIECES : p;
-            const int row = 4 * q + (lane >> 4);
-            const int slot = lane & 15;
-            const int src = (slot + 16 - ((2 * row) & 15)) & 15;     // LDS slot holds global chunk (slot - rot)
-            if (!isx) {
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            int p = wave + j * NWAVES;
+            p = p < TOT ? p : TOT - 1;
+            const int row4 = lane >> 4, slot = lane & 15;
+            if (p < PIECES) {
+                const int row = 4 * p + row4;
+                const int src = (slot + 16 - ((2 * row) & 15)) & 15;     // LDS slot holds global chunk (slot - rot)
                 int my = mb + row;
-                my = my < a.M ? my : a.M - 1;                        // tail tokens are masked in the fragments
+                my = my < a.M ? my : a.M - 1;                            // tail tokens are masked in the fragments
                 int cy = n0 + src * EPS;
-                cy = cy <= a.ldy - EPS ? cy : a.ldy - EPS;           // channels beyond the matrix are never stored
-                __builtin_amdgcn_global_load_lds((wg_gbl_void*)(dY + (size_t)my * a.ldy + cy), (wg_lds_void*)(ydst + q * 1024), 16, 0, 0);
-            } else {
-                int mx = mb + row + shift0;                          // image row r <-> token mb + shift0 + r
+                cy = cy <= a.ldy - EPS ? cy : a.ldy - EPS;               // channels beyond the matrix are never stored
+                __builtin_amdgcn_global_load_lds((wg_gbl_void*)(dY + (size_t)my * a.ldy + cy), (wg_lds_void*)(ydst + p * 1024), 16, 0, 0);
+            } else if (!SEG || p < PIECES + XPIECES) {
+                const int q = p - PIECES;
+                const int row = 4 * q + row4;
+                const int src = (slot + 16 - ((2 * row) & 15)) & 15;
+                int mx = mb + row + shift0;                              // image row r <-> token mb + shift0 + r
                 mx = mx < 0 ? 0 : (mx >= a.M ? a.M - 1 : mx);
                 int cx = c0 + src * EPS;
                 cx = cx <= a.ldx - EPS ? cx : a.ldx - EPS;
                 __builtin_amdgcn_global_load_lds((wg_gbl_void*)(X + (size_t)mx * a.ldx + cx), (wg_lds_void*)(xdst + q * 1024), 16, 0, 0);
+            } else {
+                const int q = p - PIECES - XPIECES;                      // 32 tokens' (start, end) pairs, a dword per lane
+                int dw = 2 * mb + 64 * q + lane;
+                dw = dw < 2 * a.M ? dw : 2 * a.M - 1;
+                __builtin_amdgcn_global_load_lds((wg_gbl_void*)(segw + dw), (wg_lds_void*)(ydst + SEGOFF + q * 256), 4, 0, 0);
             }
         }
     };
 
-    // transposed fragment: channel (ch0 + i) of this lane, tokens t0 + {4g..4g+3, 16+4g..16+4g+3}
+    // transposed fragment: channel (ch0 + i) of this lane, tokens t0 + {4g..4g+3, 16+4g..16+4g+3}.
+    // bf16: two ds_read_b64_tr_b16 per fragment, 16 rows (4096 B, same slot rotation) apart; the lane's byte offset
+    // inside the stage is fixed (frag_off), so a fragment step is 8 addresses and constant offsets.
+    auto frag_off = [&](int img_off, int ch0, int t0) __attribute__((always_inline)) -> unsigned {
+        const int row0 = t0 + 4 * g + (i >> 2);
+        const int col = ch0 + (i & 3) * 4;                           // first of this lane's 4 source channels
+        const int slot = col >> 3, sub = (col & 7) * 2;
+        return (unsigned)(img_off + row0 * WG_ROWB + (((slot + 2 * row0) & 15) << 4) + sub);
+    };
+    unsigned foff[8];                                                // [0..WT): dY fragments, [4..4+WT): X fragments
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            foff[k] = frag_off(0, wn * 64 + k * 16, 0);
+            foff[4 + k] = frag_off(WG_TILE_BYTES, wc * 64 + k * 16, wt);
+        }
+    }
     auto load_frag = [&](const unsigned char* img, int ch0, int t0) __attribute__((always_inline)) -> frag_t {
-        frag_t f;
-        if constexpr (sizeof(T) == 2) {
-            const int row0 = t0 + 4 * g + (i >> 2), row1 = row0 + 16;
-            const int col = ch0 + (i & 3) * 4;                       // first of this lane's 4 source channels
-            const int slot = col >> 3, sub = (col & 7) * 2;
-            const unsigned char* p0 = img + row0 * WG_ROWB + (((slot + 2 * row0) & 15) << 4) + sub;
-            const unsigned char* p1 = img + row1 * WG_ROWB + (((slot + 2 * row1) & 15) << 4) + sub;
-            const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-            const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+        frag_t f;                                                    // f32 (and only f32): scalar reads
+        const int col = ch0 + i;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                f[r] = lo4[r];
-                f[4 + r] = hi4[r];
-            }
-        } else {
-            const int col = ch0 + i;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int row = t0 + 16 * (jj >> 2) + 4 * g + (jj & 3);
-                f[jj] = *(const T*)(img + row * WG_ROWB + ((((col >> 2) + 2 * row) & 15) << 4) + (col & 3) * 4);
-            }
+        for (int jj = 0; jj < 8; ++jj) {
+            const int row = t0 + 16 * (jj >> 2) + 4 * g + (jj & 3);
+            f[jj] = *(const T*)(img + row * WG_ROWB + ((((col >> 2) + 2 * row) & 15) << 4) + (col & 3) * 4);
         }
         return f;
     };
+    const unsigned smem_addr = wg_lds_addr(smem);
 
     f32x4 acc[WT][WT];     // [c tile][n tile]: rows (4g + r) = channel c, column i = channel n
 #pragma unroll
@@ -143,64 +222,92 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
 #pragma unroll
     for (int nt = 0; nt < WT; ++nt) bsum[nt] = 0.f;
 
-    if (kb_lo < kb_hi) stage(kb_lo, 0);
-    for (int kb = kb_lo; kb < kb_hi; ++kb) {
-        __syncthreads();      // block kb landed (vmcnt(0) + barrier); every wave is done with the other stage
-        if (kb + 1 < kb_hi) stage(kb + 1, (kb + 1 - kb_lo) & 1);
-        const unsigned char* ys = smem + ((kb - kb_lo) & 1) * STAGE_BYTES;
-        const unsigned char* xs = ys + WG_TILE_BYTES;
-        const int mb = kb * WG_KT;
+    if (kb_lo < kb_hi) {
+        // every stage() issues PW instructions per wave, also past the end of the range (the last block again),
+        // so "at most (AHEAD - 1) * PW outstanding" always means "block kb has landed"
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s) stage(min(kb_lo + s, kb_hi - 1), s);
+        int cur = 0, fill = AHEAD;                 // ring slots: read / refill
+        for (int kb = kb_lo; kb < kb_hi; ++kb) {
+            wg_wait_vm_barrier<(AHEAD - 1) * PW>();   // block kb visible; every wave is done with the slot refilled next
+            stage(min(kb + AHEAD, kb_hi - 1), fill);
+            const unsigned char* ys = smem + cur * STAGE_BYTES;
+            const unsigned char* xs = ys + WG_TILE_BYTES;
+            const int2* sl = (const int2*)(ys + SEGOFF);
+            const unsigned stage_addr = smem_addr + cur * STAGE_BYTES;
+            cur = cur + 1 == NST ? 0 : cur + 1;
+            fill = fill + 1 == NST ? 0 : fill + 1;
+            const int mb = kb * WG_KT;
 
-        // does this block touch the end of the matrix or an utterance edge (for this tap)?
-        bool edge = (mb + WG_KT) > a.M;
-        if (a.seg && !edge) {
-            const int2 s0 = a.seg[mb], s1 = a.seg[mb + WG_KT - 1];
-            edge = (s0.x != s1.x) || (mb + shift < s0.x) || (mb + WG_KT - 1 + shift >= s0.y);
-        }
-        unsigned valid[2] = {0xffu, 0xffu};     // per fragment step: bit jj = token of k-slot jj contributes
-        if (edge) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                unsigned v = 0;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int m = mb + ks * 32 + 16 * (jj >> 2) + 4 * g + (jj & 3);
-                    bool ok = m < a.M;
-                    if (ok && a.seg) {
-                        const int2 s = a.seg[m];
-                        ok = (m + shift >= s.x) && (m + shift < s.y);
-                    }
-                    v |= (ok ? 1u : 0u) << jj;
-                }
-                valid[ks] = v;
+            // does this block touch the end of the matrix or an utterance edge (for this tap)?
+            bool edge = (mb + WG_KT) > a.M;
+            if (SEG && !edge) {
+                int2 s0;
+                int s1;
+                wg_lds_read_first_last(sl, s0, s1);
+                const int s0x = __builtin_amdgcn_readfirstlane(s0.x), s0y = __builtin_amdgcn_readfirstlane(s0.y);
+                const int s1x = __builtin_amdgcn_readfirstlane(s1);
+                edge = (s0x != s1x) || (mb + shift < s0x) || (mb + WG_KT - 1 + shift >= s0y);
             }
-        }
-
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            frag_t yf[WT], xf[WT];
-#pragma unroll
-            for (int nt = 0; nt < WT; ++nt) yf[nt] = load_frag(ys, wn * (16 * WT) + nt * 16, ks * 32);
-#pragma unroll
-            for (int ct = 0; ct < WT; ++ct) xf[ct] = load_frag(xs, wc * (16 * WT) + ct * 16, ks * 32 + wt);
+            unsigned valid[2] = {0xffu, 0xffu};     // per fragment step: bit jj = token of k-slot jj contributes
             if (edge) {
 #pragma unroll
-                for (int nt = 0; nt < WT; ++nt)
+                for (int ks = 0; ks < 2; ++ks) {
+                    unsigned v = 0;
+                    int2 sg[8];
+                    if (SEG) wg_lds_read_rows8(sl + ks * 32 + 4 * g, sg);
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj)
-                        if (!((valid[ks] >> jj) & 1u)) yf[nt][jj] = (T)0.0f;
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int r = ks * 32 + 16 * (jj >> 2) + 4 * g + (jj & 3);
+                        const int m = mb + r;
+                        bool ok = m < a.M;
+                        if (SEG) ok = ok && (m + shift >= sg[jj].x) && (m + shift < sg[jj].y);
+                        v |= (ok ? 1u : 0u) << jj;
+                    }
+                    valid[ks] = v;
+                }
             }
-            if (do_bias) {
+
 #pragma unroll
-                for (int nt = 0; nt < WT; ++nt)
+            for (int ks = 0; ks < 2; ++ks) {
+                frag_t yf[WT], xf[WT];
+                if constexpr (sizeof(T) == 2) {
+                    unsigned ad[8];
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) bsum[nt] += to_f32(yf[nt][jj]);
+                    for (int k = 0; k < 8; ++k) ad[k] = stage_addr + foff[k];
+                    bf16x8 fr[8];
+                    if (ks == 0) wg_tr_read16<0>(ad, fr); else wg_tr_read16<32 * WG_ROWB>(ad, fr);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        yf[k] = fr[k];
+                        xf[k] = fr[4 + k];
+                    }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < WT; ++nt) yf[nt] = load_frag(ys, wn * (16 * WT) + nt * 16, ks * 32);
+#pragma unroll
+                    for (int ct = 0; ct < WT; ++ct) xf[ct] = load_frag(xs, wc * (16 * WT) + ct * 16, ks * 32 + wt);
+                }
+                if (edge) {
+#pragma unroll
+                    for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj)
+                            if (!((valid[ks] >> jj) & 1u)) yf[nt][jj] = (T)0.0f;
+                }
+                if (do_bias) {
+#pragma unroll
+                    for (int nt = 0; nt < WT; ++nt)
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) bsum[nt] += to_f32(yf[nt][jj]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < WT; ++ct)
+#pragma unroll
+                    for (int nt = 0; nt < WT; ++nt) acc[ct][nt] = mma16(xf[ct], yf[nt], acc[ct][nt]);
             }
-#pragma unroll
-            for (int ct = 0; ct < WT; ++ct)
-#pragma unroll
-                for (int nt = 0; nt < WT; ++nt) acc[ct][nt] = mma16(xf[ct], yf[nt], acc[ct][nt]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the refills past the end still target this workgroup's LDS
     }
     if (do_bias) {
 #pragma unroll
@@ -290,28 +397,37 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
         const int bch = dtype == 0 ? 64 : 128;
         a.n_tiles = (N + bch - 1) / bch;
         a.c_tiles = (Cin + bch - 1) / bch;
-        const bool tw3 = taps % 3 == 0;
-        const int lds = 2 * (WG_TILE_BYTES + ((WG_KT + (tw3 ? 2 : 0) + 3) / 4) * 1024);
+        const bool tw3 = taps % 3 == 0, has_seg = taps > 1;
+        if (!has_seg) a.seg = nullptr;
+        const int tw = tw3 ? 3 : 1;
+        const int lds = wgrad_stages(tw) * ((16 + (WG_KT + tw - 1 + 3) / 4) * 1024 + (has_seg ? 512 : 0));
         static bool attr_set = false;
         if (!attr_set) {
-            const int big = 2 * (WG_TILE_BYTES + 17 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            const int big = 3 * (33 * 1024 + 512);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
             attr_set = true;
         }
         dim3 grid(a.n_tiles * a.c_tiles * (tw3 ? taps / 3 : taps), ksplit);
         if (tw3) {
             if (dtype == 0)
-                hipLaunchKernelGGL((conv_wgrad_kernel<float, 3>), grid, dim3(768), lds, stream, a);
+                hipLaunchKernelGGL((conv_wgrad_kernel<float, 3, true>), grid, dim3(768), lds, stream, a);
             else
-                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3>), grid, dim3(768), lds, stream, a);
+                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 3, true>), grid, dim3(768), lds, stream, a);
+        } else if (has_seg) {
+            if (dtype == 0)
+                hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, true>), grid, dim3(256), lds, stream, a);
+            else
+                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 1, true>), grid, dim3(256), lds, stream, a);
         } else {
             if (dtype == 0)
-                hipLaunchKernelGGL((conv_wgrad_kernel<float, 1>), grid, dim3(256), lds, stream, a);
+                hipLaunchKernelGGL((conv_wgrad_kernel<float, 1, false>), grid, dim3(256), lds, stream, a);
             else
-                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 1>), grid, dim3(256), lds, stream, a);
+                hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 1, false>), grid, dim3(256), lds, stream, a);
         }
         FS2_CHECK_LAUNCH("fs2_conv_wgrad");
     } else {
