@@ -235,7 +235,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
     typedef typename TL::frag_t frag_t;
     constexpr int KS = TL::KS, DT = TL::DT, TILE = TL::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // stage s: Q image at smem + s * 2 * TILE, dO image behind it (both rotation 2: read both ways)
+    // stage s: Q image at smem + s * STAGE, dO image behind it (both rotation 2: read both ways), then the 64
+    // lse and 64 delta values of those query rows.  They come by the same DMA: an ordinary global load inside the
+    // loop would make hipcc drain the prefetch (vmcnt(0)) at every use.
+    constexpr int STAGE = 2 * TILE + 512;
 
     const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
     const int r0 = a.cu[b];
@@ -266,16 +269,23 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
 
     const int ntiles = (len + AB_BT - 1) / AB_BT;
     auto stage = [&](int qt, int st) __attribute__((always_inline)) {
-        unsigned char* qd = smem + st * 2 * TILE;
+        unsigned char* qd = smem + st * STAGE;
         TL::template stage<2>(base, a.ld, qcol, qt * AB_BT, len, qd, wave, lane);
         TL::template stage<2>(dob, a.ldo, qcol, qt * AB_BT, len, qd + TILE, wave, lane);
+        if (wave < 2) {
+            int q = qt * AB_BT + lane;
+            q = q < len ? q : len - 1;
+            __builtin_amdgcn_global_load_lds((ab_gbl_void*)((wave ? delta : lse) + q),
+                                             (ab_lds_void*)(qd + 2 * TILE + wave * 256), 4, 0, 0);
+        }
     };
     stage(0, 0);
     for (int qt = 0; qt < ntiles; ++qt) {
         __syncthreads();
         if (qt + 1 < ntiles) stage(qt + 1, (qt + 1) & 1);
-        const unsigned char* Qs = smem + (qt & 1) * 2 * TILE;
+        const unsigned char* Qs = smem + (qt & 1) * STAGE;
         const unsigned char* Ds = Qs + TILE;
+        const float* lse_s = (const float*)(Qs + 2 * TILE);
         const int q0 = qt * AB_BT;
 
         f32x4 s[4], dp[4];
@@ -292,17 +302,20 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
             }
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 lse4 = *(const f32x4*)(lse_s + nt * 16 + 4 * g);
+            const f32x4 del4 = *(const f32x4*)(lse_s + 64 + nt * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + nt * 16 + 4 * g + r;
                 const bool ok = q < len;
                 const int qc = ok ? q : len - 1;
-                const float p = ok ? __builtin_amdgcn_exp2f(s[nt][r] * a.scale_log2e - lse[qc]) : 0.f;
+                const float p = ok ? __builtin_amdgcn_exp2f(s[nt][r] * a.scale_log2e - lse4[r]) : 0.f;
                 const float mul = a.drop.thresh ? drop_mul(dh, (uint32_t)(r0 + qc), (uint32_t)kc) : 1.0f;
-                dp[nt][r] = p * (dp[nt][r] * mul - delta[qc]);
+                dp[nt][r] = p * (dp[nt][r] * mul - del4[r]);
                 s[nt][r] = p * mul;                      // dV uses the dropped probabilities
             }
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             frag_t pf, dsf;
@@ -338,15 +351,16 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
 template <typename T, int DK>
 static int launch_attention_bwd(const AttnBwdArgs& a, int B, int H, int max_len, hipStream_t stream) {
     constexpr int lds = 2 * 2 * AB_BT * DK * (int)sizeof(T);
+    constexpr int lds_dkv = lds + 2 * 512;            // + lse / delta rows of both stages
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
         attr_set = true;
     }
     dim3 grid((max_len + AB_BT - 1) / AB_BT, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DK>), grid, dim3(AB_THREADS), lds, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DK>), grid, dim3(AB_THREADS), lds, stream, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DK>), grid, dim3(AB_THREADS), lds_dkv, stream, a);
     FS2_CHECK_LAUNCH("fs2_attention_bwd");
     return FS2_OK;
 }

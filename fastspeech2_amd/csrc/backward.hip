@@ -8,7 +8,10 @@
 namespace fs2 {
 
 constexpr int LNB_MAXV = 4;          // float4 per lane -> C <= 1024
-constexpr int LNB_ROWS = 32;         // rows per workgroup (4 waves x 8 rows)
+#ifndef FS2_LNB_ROWS
+#define FS2_LNB_ROWS 32
+#endif
+constexpr int LNB_ROWS = FS2_LNB_ROWS;   // rows per workgroup (4 waves x LNB_ROWS / 4 rows)
 
 // g = dy + sum_p parts[p];  LayerNorm backward through x (statistics recomputed from x):
 //   xh = (x - mean) * rstd,  h = g * w,  dx = rstd * (h - mean(h) - xh * mean(h * xh))

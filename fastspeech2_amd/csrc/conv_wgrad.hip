@@ -342,13 +342,17 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
 }
 
 // grad[n][c][tap] (the nn.Conv1d / nn.Linear parameter layout) = scale * sum_s part[s][tap][n][c]
-// (+ grad when accumulate != 0)
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad, int ksplit, int taps,
-                                         long long NC, float scale, int accumulate,
-                                         const float* __restrict__ bias_part, float* __restrict__ dbias, int N) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= NC) {
-        const long long n = idx - NC;
+// (+ grad when accumulate != 0).  A workgroup sums 256 (n, c) positions tap by tap (coalesced reads of every
+// partial), turns the [tap][256] block into [256][tap] in LDS and writes 256 * taps consecutive floats.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ grad,
+                                                                int ksplit, int taps, long long NC, float scale,
+                                                                int accumulate, const float* __restrict__ bias_part,
+                                                                float* __restrict__ dbias, int N) {
+    __shared__ float tile[256 * 9];
+    const int tid = threadIdx.x;
+    const long long idx0 = (long long)blockIdx.x * 256;
+    if (idx0 >= NC) {                                   // trailing workgroups: the bias gradient
+        const long long n = idx0 - (NC + 255) / 256 * 256 + tid;
         if (dbias && n < N) {
             float s = 0.f;
             for (int k = 0; k < ksplit; ++k) s += bias_part[(size_t)k * N + n];
@@ -357,13 +361,25 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* 
         }
         return;
     }
-    for (int t = 0; t < taps; ++t) {
-        float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += part[((size_t)k * taps + t) * NC + idx];
-        s *= scale;
-        float* dst = grad + idx * taps + t;
-        *dst = accumulate ? *dst + s : s;
+    const long long idx = idx0 + tid;
+    if (idx < NC) {
+        for (int t = 0; t < taps; ++t) {
+            const float* src = part + (size_t)t * NC + idx;
+            float s0 = 0.f, s1 = 0.f;
+            int k = 0;
+            for (; k + 1 < ksplit; k += 2) {
+                s0 += src[(size_t)k * taps * NC];
+                s1 += src[(size_t)(k + 1) * taps * NC];
+            }
+            if (k < ksplit) s0 += src[(size_t)k * taps * NC];
+            tile[tid * taps + t] = (s0 + s1) * scale;
+        }
     }
+    __syncthreads();
+    const long long left = NC - idx0;
+    const int total = (int)(left < 256 ? left : 256) * taps;
+    float* dst = grad + idx0 * taps;
+    for (int o = tid; o < total; o += 256) dst[o] = accumulate ? dst[o] + tile[o] : tile[o];
 }
 
 }  // namespace fs2
@@ -433,7 +449,7 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
     } else {
         (void)hipMemsetAsync(workspace, 0, (size_t)fs2_conv_wgrad_workspace(N, Cin, taps, ksplit), stream);
     }
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((NC + (dbias ? N : 0) + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((NC + 255) / 256 + (dbias ? (N + 255) / 256 : 0))), dim3(256), 0, stream,
                        workspace, grad, ksplit, taps, NC, scale, accumulate, bias_part, dbias, N);
     FS2_CHECK_LAUNCH("fs2_conv_wgrad(reduce)");
     return FS2_OK;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# tools/build_variant.sh TAG -DFOO=1 ...   ->  variants/libfs2_TAG.so (use with FS2_LIB=variants/libfs2_TAG.so)
+set -e
+cd "$(dirname "$0")/.."
+tag=$1; shift
+mkdir -p variants/obj_$tag
+objs=""
+for src in fastspeech2_amd/csrc/*.hip; do
+  o=variants/obj_$tag/$(basename ${src%.hip}).o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I fastspeech2_amd/csrc "$@" -c $src -o $o &
+  objs="$objs $o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libfs2_$tag.so $objs
+rm -rf variants/obj_$tag
+echo variants/libfs2_$tag.so
