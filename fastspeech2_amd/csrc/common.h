@@ -75,6 +75,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- LDS-DMA pipelines that span a barrier ----------------------------------------------------
+// `s_waitcnt vmcnt(N)` retires all but this wave's N youngest vector-memory instructions, then a raw s_barrier
+// (a __syncthreads() would wait vmcnt(0) and drain every LDS-DMA still in flight).
+template <int N> __device__ __forceinline__ void vm_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // ---- dropout (training only) --------------------------------------------------------------
 // Counter-based: element (row, col) of dropout site `stream` is kept iff hash(seed, stream, row, col) >= thresh,
 // thresh = rate * 2^32; kept values are scaled by 1 / (1 - rate) (nn.Dropout).  The same function is

@@ -44,12 +44,6 @@ constexpr int wgrad_stages(int tw) { return tw == 3 ? 3 : 2; }     // ring depth
 typedef __attribute__((address_space(3))) void wg_lds_void;
 typedef const __attribute__((address_space(1))) void wg_gbl_void;
 
-template <int N>
-__device__ __forceinline__ void wg_wait_vm_barrier() {
-    // stage retired for this wave (at most N younger DMA instructions outstanding), then every wave's
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-
 // LDS reads of the staged seg rows, as asm: behind an ordinary LDS load hipcc puts s_waitcnt vmcnt(0) while an
 // LDS-DMA is in flight (it cannot tell the images apart), which would serialise the ring.
 typedef int wg_i4 __attribute__((ext_vector_type(4)));
@@ -229,7 +223,7 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
         for (int s = 0; s < AHEAD; ++s) stage(min(kb_lo + s, kb_hi - 1), s);
         int cur = 0, fill = AHEAD;                 // ring slots: read / refill
         for (int kb = kb_lo; kb < kb_hi; ++kb) {
-            wg_wait_vm_barrier<(AHEAD - 1) * PW>();   // block kb visible; every wave is done with the slot refilled next
+            vm_wait_barrier<(AHEAD - 1) * PW>();   // block kb visible; every wave is done with the slot refilled next
             stage(min(kb + AHEAD, kb_hi - 1), fill);
             const unsigned char* ys = smem + cur * STAGE_BYTES;
             const unsigned char* xs = ys + WG_TILE_BYTES;

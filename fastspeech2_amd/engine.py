@@ -176,20 +176,10 @@ class Engine:
 
     @staticmethod
     def _ksplit(M, N, Cin, taps, code):
-        """Split-K factor for a GEMM whose 128x128 tiling would leave most CUs idle (phone-level
-        stacks, batch-1 decoding).  Only used where an add+LayerNorm kernel consumes the partials."""
-        nch = -(-Cin // (64 if code == BF16 else 32))
-        blocks = -(-M // 128) * -(-N // 128)
-        if 200 <= blocks < 600 and nch * taps >= 64:
-            # narrow output, long K (second FFN conv at frame level): ~400 workgroups leave the CUs with one or two
-            # resident each; three K ranges (~1200 workgroups, 3 per CU) measured 82 vs 89 us per launch
-            return 3
-        if blocks >= 200 or nch * taps < 32:
-            return 1
-        ks = max(1, min(nch, 8, 256 // blocks))
-        while ks > 1 and (nch // ks) * taps < 8:
-            ks -= 1
-        return ks
+        """Split-K factor for a GEMM whose tiling would leave most CUs idle (phone-level stacks, batch-1
+        decoding, the narrow second FFN conv).  Only used where an add+LayerNorm kernel consumes the partials.
+        The rule lives beside the kernel dispatch (csrc/conv_gemm.hip: fs2_conv_gemm_ksplit)."""
+        return int(hip.load().fs2_conv_gemm_ksplit(int(M), int(N), int(Cin), int(taps), int(code)))
 
     def _gemm(self, x, w, bias, M, N, Cin, taps, code, seg=None, res=None, relu=False, out_f32=False, tag=None,
               ksplit=1, out=None):

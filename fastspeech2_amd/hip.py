@@ -67,7 +67,12 @@ _SIZE_QUERIES = {
     "fs2_layernorm_bwd_workspace": [_I, _I],
     "fs2_colreduce_workspace": [_I, _I, _I],
 }
-EXPORTS = sorted(list(_SIGNATURES) + list(_SIZE_QUERIES) + ["fs2_last_error", "fs2_abi_version", "fs2_device_arch"])
+# plain int queries (no launch, cannot fail)
+_INT_QUERIES = {
+    "fs2_conv_gemm_ksplit": [_I, _I, _I, _I, _I],
+}
+EXPORTS = sorted(list(_SIGNATURES) + list(_SIZE_QUERIES) + list(_INT_QUERIES) +
+                 ["fs2_last_error", "fs2_abi_version", "fs2_device_arch"])
 
 
 def lib_path() -> str:
@@ -92,6 +97,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = c_longlong
+    for name, argtypes in _INT_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
     lib.fs2_last_error.restype = c_char_p
     lib.fs2_abi_version.restype = c_int
     lib.fs2_device_arch.argtypes = [c_char_p, c_int]

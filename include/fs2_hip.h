@@ -79,6 +79,11 @@ int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* 
                   int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int out_f32, int dtype,
                   int ksplit, long long split_stride, hipStream_t stream);
 
+/* Split-K factor (>= 1) the launch schedules pass as `ksplit` for a GEMM of this shape whose partial outputs
+ * an fs2_add_layernorm call sums: 1 unless the tiling would leave most CUs idle.  No launch; no counterpart in
+ * the reference (it is part of the kernel dispatch). */
+int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype);
+
 /* Fused varlen multi-head self-attention (scores, softmax, P.V) over packed qkv [M, ld] T laid out
  * q | k | v with each part [n_heads][dk]; ctx [M, ldo] T.  dk in {32, 64, 96, 128}.
  * Replaces MultiHeadedAttention.forward between the projections (network/encoder.py:73-88). */

@@ -92,6 +92,62 @@ def test_conv_gemm(dtype, taps, cin, n, lens):
         assert err <= t * max(1.0, exp.abs().max().item()), (relu, use_res, out_f32, err)
 
 
+@pytest.mark.parametrize("cin,n,ksplit,lens", [
+    (256, 1024, 1, [700, 3, 1, 64, 192, 191, 193, 2900, 8, 4300]),      # 45 x 4 tiles of 192 x 256
+    (1024, 256, 4, [1, 190, 2, 8300, 59]),                               # 45 x 1 tiles, four K ranges
+    (256, 512, 1, [192 * 85 + 7]),                                       # one long utterance, ragged last tile
+])
+def test_conv_gemm_big_tile(cin, n, ksplit, lens):
+    """the 192 x 256 / ring-of-three-stages kernel the frame-level FFN convs take (bf16, 9 taps), against torch's
+    fp32 conv of the same bf16-rounded operands, utterance by utterance"""
+    taps, code, tdt = 9, hip.DTYPE_CODE["bf16"], torch.bfloat16
+    g = torch.Generator().manual_seed(cin + n + ksplit)
+    M = sum(lens)
+    x = torch.randn(M, cin, generator=g)
+    w = torch.randn(n, cin, taps, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(n, generator=g) * 0.1
+    res = torch.randn(M, n, generator=g)
+    xd, bd, rd = x.to(DEV, tdt).contiguous(), b.to(DEV), res.to(DEV)
+    wd = w.permute(2, 0, 1).to(DEV, tdt).contiguous()
+    wq = w.to(DEV, tdt).float()
+    outs, r0 = [], 0
+    for L in lens:
+        xi = xd[r0:r0 + L].float().t().unsqueeze(0)
+        outs.append(F.conv1d(xi, wq, bd, padding=4).squeeze(0).t())
+        r0 += L
+    ref = torch.cat(outs, 0)
+    _, _, seg, _ = _seg_tables(lens)
+    scale = max(1.0, ref.abs().max().item())
+    if ksplit == 1:
+        for relu, use_res, out_f32 in [(False, False, True), (True, False, False), (False, True, True)]:
+            out = torch.full((M, n), float("nan"), device=DEV, dtype=torch.float32 if out_f32 else tdt)
+            call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), ptr(rd) if use_res else None, ptr(out), ptr(seg), M, n, cin,
+                 taps, cin, n, n, int(relu), int(out_f32), code, 1, 0, stream())
+            exp = ref.clamp_min(0) if relu else ref
+            exp = exp + rd if use_res else exp
+            err = (out.float() - exp).abs().max().item()
+            assert err <= (2e-3 if out_f32 else 1e-2) * scale, (relu, use_res, out_f32, err)
+    else:
+        parts = torch.full((ksplit, M, n), float("nan"), device=DEV)
+        call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), None, ptr(parts), ptr(seg), M, n, cin, taps, cin, n, n, 0, 1, code,
+             ksplit, M * n, stream())
+        err = (parts.sum(0) - ref).abs().max().item()
+        assert err <= 2e-3 * scale, err
+    torch.cuda.synchronize()
+
+
+def test_conv_gemm_ksplit_rule():
+    ks = hip.load().fs2_conv_gemm_ksplit
+    assert ks(24400, 1024, 256, 9, 1) == 1          # frame-level first FFN conv: 512 big tiles
+    assert ks(24400, 256, 1024, 9, 1) == 2          # second: 128 tiles of 192 x 256 -> two K ranges, one per CU
+    assert ks(24400, 256, 1024, 9, 0) == 3          # fp32 stays on the 128 x 128 kernel
+    assert ks(0, 256, 256, 1, 1) == 1
+    for M, N, C, t in [(120, 256, 1024, 9), (4000, 768, 256, 1), (3900, 256, 1024, 9), (700, 80, 256, 1)]:
+        for code in (0, 1):
+            k = ks(M, N, C, t, code)
+            assert 1 <= k <= 16 and k <= -(-C // (64 if code else 32))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("taps,cin,n,lens,ksplit", [(9, 1024, 256, [150, 140], 4), (1, 256, 256, [77], 3),
                                                     (3, 96, 64, [30, 9], 2)])
