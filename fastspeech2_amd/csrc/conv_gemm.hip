@@ -414,172 +414,6 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     conv_epilogue<T, MT, NT>(a, bias, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Big-tile form for the frame-level FFN convs (bf16, 9 taps, Cin % 64 == 0, enough tiles to fill the chip).
-// The 128 x 128 kernel above keeps ONE W stage per workgroup in flight and retires it (vmcnt(0)) at every
-// barrier: with three workgroups per CU that is 48 KB in flight per CU, and at ~2 us of loaded L2 latency the
-// kernel stalls at about a third of the MFMA rate.  Here one workgroup of 8 waves owns a CU: tile 192 tokens x
-// 256 channels (wave tile 96 x 64), so a W byte feeds twice the MFMAs; the W stages (256 rows x 128 B) form a ring
-// of three filled two (tap, chunk) steps ahead, the X image (200 rows) of the next channel chunk is fetched nine
-// steps ahead into a second buffer, and the loop waits with counted `s_waitcnt vmcnt(N)` + raw s_barrier, never
-// for the youngest stage.  LDS: 2 x 25,600 + 3 x 32,768 = 149,504 B.
-// Every wave issues the same number of DMA instructions per stage (4 for W, 4 for X with the last piece repeated),
-// which is what makes the counts below compile-time constants.
-constexpr int CB_MT = 6, CB_NT = 4, CB_WM = 2, CB_WN = 4, CB_NW = CB_WM * CB_WN;
-constexpr int CB_BM = 16 * CB_MT * CB_WM, CB_BN = 16 * CB_NT * CB_WN;      // 192 x 256
-constexpr int CB_TAPS = 9, CB_PAD = 4;
-constexpr int CB_XROWS = CB_BM + CG_HALO;
-constexpr int CB_X_BYTES = CB_XROWS * CG_ROWB, CB_W_BYTES = CB_BN * CG_ROWB;
-constexpr int CB_X_INSTR = CB_XROWS / 8, CB_W_INSTR = CB_BN / 8;           // 25, 32 one-KiB pieces
-constexpr int CB_XPW = (CB_X_INSTR + CB_NW - 1) / CB_NW, CB_WPW = CB_W_INSTR / CB_NW;   // 4, 4 per wave
-constexpr int CB_WSTAGES = 3;
-constexpr int CB_LDS = 2 * CB_X_BYTES + CB_WSTAGES * CB_W_BYTES;
-static_assert(CB_W_INSTR % CB_NW == 0 && CB_XROWS % 8 == 0, "uniform DMA counts per wave");
-
-__global__ __launch_bounds__(64 * CB_NW, 2) void conv_gemm_big_kernel(ConvGemmArgs a) {
-    typedef bf16_t T;
-    typedef Frag<T>::type frag_t;
-    constexpr int MT = CB_MT, NT = CB_NT, EPV = 8, BKE = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [X buf 0][X buf 1][W stage 0][W stage 1][W stage 2]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int g = lane >> 4, i = lane & 15;
-
-    int n_tile, m_tile;                      // XCD-aware order, as in conv_gemm_kernel
-    if (a.xcd_sets > 0) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        const int set = xcd % a.xcd_sets, member = xcd / a.xcd_sets;
-        n_tile = set * a.xcd_group + slot % a.xcd_group;
-        m_tile = (slot / a.xcd_group) * (8 / a.xcd_sets) + member;
-        if (m_tile >= a.m_tiles) return;
-    } else {
-        n_tile = blockIdx.x % a.n_tiles;
-        m_tile = blockIdx.x / a.n_tiles;
-    }
-    const int m0 = m_tile * CB_BM, n0 = n_tile * CB_BN;
-    const int nchunks_all = a.Cin / BKE;
-    const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;
-    const int chunk_lo = blockIdx.y * cps;
-    const int chunk_hi = min(nchunks_all, chunk_lo + cps);
-    const int nsteps = max(chunk_hi - chunk_lo, 0) * CB_TAPS;
-    const float* bias = blockIdx.y == 0 ? a.bias : nullptr;
-    const T* __restrict__ X = (const T*)a.X;
-    const T* __restrict__ W = (const T*)a.W;
-
-    int lo[MT], hi[MT];                      // per-lane validity window of tap shifts for each of its token rows
-    bool edge = false;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * (16 * MT) + mt * 16 + i;
-        int l = 1, h = 0;
-        if (m < a.M) {
-            const int2 sg = a.seg[m];
-            l = sg.x - m;
-            h = sg.y - 1 - m;
-        }
-        lo[mt] = l;
-        hi[mt] = h;
-        edge |= (l > -CB_PAD) | (h < CB_PAD);
-    }
-    const bool need_mask = __syncthreads_or(edge ? 1 : 0) != 0;    // (no DMA in flight yet)
-
-    const int prow = lane >> 3, pslot = lane & 7;
-    auto stage_x = [&](int chunk, int buf) __attribute__((always_inline)) {
-        unsigned char* dst = smem + buf * CB_X_BYTES;
-        const int c0 = chunk * BKE;
-#pragma unroll
-        for (int q = 0; q < CB_XPW; ++q) {
-            int p = wave + CB_NW * q;
-            p = p < CB_X_INSTR ? p : CB_X_INSTR - 1;
-            const int r = 8 * p + prow;
-            int gm = m0 - CB_PAD + r;
-            gm = gm < 0 ? 0 : (gm >= a.M ? a.M - 1 : gm);          // out-of-range rows are always masked
-            glds16(X + (size_t)gm * a.ldx + c0 + ((pslot ^ swz_x(r)) * EPV), dst + p * 1024);
-        }
-    };
-    auto stage_w = [&](int step, int slot) __attribute__((always_inline)) {   // step = (chunk - chunk_lo) * 9 + tap
-        unsigned char* dst = smem + 2 * CB_X_BYTES + slot * CB_W_BYTES;
-        const int chunk = chunk_lo + step / CB_TAPS, tap = step % CB_TAPS;
-        const T* wt = W + (size_t)tap * a.N * a.Cin + chunk * BKE;
-#pragma unroll
-        for (int q = 0; q < CB_WPW; ++q) {
-            const int p = wave + CB_NW * q;
-            const int r = 8 * p + prow;
-            int n = n0 + r;
-            n = n >= a.N ? a.N - 1 : n;                            // columns >= N are never stored
-            glds16(wt + (size_t)n * a.Cin + ((pslot ^ swz_w(r)) * EPV), dst + p * 1024);
-        }
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int wrow_base = wn * (16 * NT) + (i >> 2) * (4 * NT) + (i & 3);     // W row order: see conv_gemm_kernel
-    const int xrow_base = wm * (16 * MT) + i;
-
-    if (nsteps > 0) {
-        stage_x(chunk_lo, 0);
-        stage_w(0, 0);
-        stage_w(min(1, nsteps - 1), 1);
-        int tap = 0, chunk = chunk_lo, xbuf = 0, wslot = 0, fill = 2;
-        for (int step = 0; step < nsteps; ++step) {
-            // W(step) — and everything older — has landed; W(step + 1) may still be in flight, and so may the X image
-            // issued at tap 0 of this chunk (it sits between W(step + 1) and W(step + 2) in issue order at tap 1,
-            // behind W(step) and before W(step + 1) at tap 2)
-            const bool x_young = (tap == 1 || tap == 2) && (chunk + 1 < chunk_hi);
-            if (x_young)
-                vm_wait_barrier<CB_WPW + CB_XPW>();
-            else
-                vm_wait_barrier<CB_WPW>();
-            stage_w(min(step + 2, nsteps - 1), fill);             // past the end: the last stage again (equal counts)
-            if (tap == 0 && chunk + 1 < chunk_hi) stage_x(chunk + 1, xbuf ^ 1);
-
-            const unsigned char* xs = smem + xbuf * CB_X_BYTES;
-            const unsigned char* ws = smem + 2 * CB_X_BYTES + wslot * CB_W_BYTES;
-            const int shift = tap - CB_PAD;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                frag_t wf[NT], xf[MT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int r = wrow_base + 4 * nt;
-                    wf[nt] = *(const frag_t*)(ws + r * CG_ROWB + (((ks * 4 + g) ^ swz_w(r)) << 4));
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int r = xrow_base + mt * 16 + tap;
-                    xf[mt] = *(const frag_t*)(xs + r * CG_ROWB + (((ks * 4 + g) ^ swz_x(r)) << 4));
-                }
-                if (need_mask) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        if (shift < lo[mt] || shift > hi[mt]) xf[mt] = frag_zero<T>();
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(wf[nt], xf[mt], acc[mt][nt]);
-            }
-            wslot = wslot + 1 == CB_WSTAGES ? 0 : wslot + 1;
-            fill = fill + 1 == CB_WSTAGES ? 0 : fill + 1;
-            if (++tap == CB_TAPS) {
-                tap = 0;
-                ++chunk;
-                xbuf ^= 1;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the refills past the end target this workgroup's LDS
-    }
-    conv_epilogue<T, MT, NT>(a, bias, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
-}
-
 // XCD-aware tile order for a BM x BN tiling (see conv_gemm_kernel); returns the x grid size
 static int conv_gemm_plan_grid(ConvGemmArgs& a, int BM, int BN, size_t elem) {
     a.n_tiles = (a.N + BN - 1) / BN;
@@ -605,26 +439,6 @@ static int conv_gemm_plan_grid(ConvGemmArgs& a, int BM, int BN, size_t elem) {
     return grid_x;
 }
 
-// does the big-tile kernel take this problem?  (bf16 FFN-conv shapes with at least ~2/3 of the CUs busy)
-static bool conv_gemm_big_ok(int M, int N, int Cin, int taps, int dtype, int ksplit) {
-    static const int mode = getenv("FS2_CONV_BIG") ? atoi(getenv("FS2_CONV_BIG")) : 1;
-    if (!mode || dtype != 1 || taps != CB_TAPS || Cin % 64 != 0 || N < CB_BN) return false;
-    const long tiles = (long)((M + CB_BM - 1) / CB_BM) * ((N + CB_BN - 1) / CB_BN) * ksplit;
-    return tiles >= 170;
-}
-
-static int launch_conv_gemm_big(ConvGemmArgs a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CB_LDS);
-        attr_set = true;
-    }
-    const int grid_x = conv_gemm_plan_grid(a, CB_BM, CB_BN, sizeof(bf16_t));
-    hipLaunchKernelGGL(conv_gemm_big_kernel, dim3(grid_x, a.ksplit), dim3(64 * CB_NW), CB_LDS, stream, a);
-    FS2_CHECK_LAUNCH("fs2_conv_gemm(big)");
-    return FS2_OK;
-}
-
 template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
@@ -648,9 +462,6 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const bool dma = (a.Cin % BKE) == 0;
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
     const bool small = big_blocks < 200;   // would leave most of the 256 CUs idle: use 64x64 tiles
-    if constexpr (sizeof(T) == 2) {
-        if (conv_gemm_big_ok(a.M, a.N, a.Cin, a.taps, 1, a.ksplit)) return launch_conv_gemm_big(a, stream);
-    }
     if (!dma) return small ? launch_conv_gemm<T, 2, 2, 2, 0, true, 2>(a, stream) : launch_conv_gemm<T, 4, 4, 2, 0, true, 2>(a, stream);
     if (small) return launch_conv_gemm<T, 2, 2, 2, 1, false, 4>(a, stream);
     // 128x128 (MT = 4), X image single-buffered: 50 KB of LDS -> 3 workgroups per CU.  Measured on MI355X (config-2
@@ -660,7 +471,12 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // 96-row tiles spread them over the CUs more evenly (measured 157 vs 167 us on 25 k x 256 x 9216; 128 rows
     // stay better everywhere else, 64 rows nowhere; a 256 x 128 block of 128 x 64 wave tiles — fewer LDS reads
     // per MFMA, 2 workgroups per CU — measured 145 / 202 us against 136 / 166 us on the two FFN convs: the
-    // kernel is bound by latency hiding, not by LDS bandwidth).  FS2_CONV_MT=2|3|4 forces a tile height (experiments).
+    // kernel is bound by latency hiding, not by LDS bandwidth).  A 192 x 256 tile on 8 waves, one workgroup per CU,
+    // with the W stages in a ring of three behind counted `s_waitcnt vmcnt(N)` + raw s_barrier (what conv_wgrad.hip
+    // does; git history: "experimental 192x256 big-tile kernel") read 0.7x the bytes through L2 but ran the decoder
+    // convs in 148 / 149 us against 118 / 123 us here: 536 workgroups at one per CU take three rounds, and inside
+    // a round the waves still spent a third of their time in the stage wait (SQ_WAIT_INST_ANY 36 %, MFMA busy 33 %).
+    // FS2_CONV_MT=2|3|4 forces a tile height (experiments).
     static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
     int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
     if (forced) best = forced;
@@ -714,14 +530,6 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
 extern "C" int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype) {
     const int nch = (Cin + (dtype == 1 ? 64 : 32) - 1) / (dtype == 1 ? 64 : 32);
     if (M <= 0) return 1;
-    {   // big-tile kernel: one workgroup per CU; split K while the tiles cover less than half of the chip
-        const long tiles = (long)((M + fs2::CB_BM - 1) / fs2::CB_BM) * ((N + fs2::CB_BN - 1) / fs2::CB_BN);
-        int ks = (int)(256 / (tiles > 0 ? tiles : 1));
-        ks = ks > 4 ? 4 : ks;
-        while (ks > 1 && nch % ks != 0) --ks;
-        if (ks >= 2 && tiles >= 64 && fs2::conv_gemm_big_ok(M, N, Cin, taps, dtype, ks)) return ks;
-        if (fs2::conv_gemm_big_ok(M, N, Cin, taps, dtype, 1)) return 1;
-    }
     const long blocks = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (blocks >= 200 && blocks < 600 && nch * taps >= 64) {
         // narrow output, long K (second FFN conv at frame level): ~400 workgroups leave the CUs with one or two

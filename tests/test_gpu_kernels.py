@@ -93,13 +93,13 @@ def test_conv_gemm(dtype, taps, cin, n, lens):
 
 
 @pytest.mark.parametrize("cin,n,ksplit,lens", [
-    (256, 1024, 1, [700, 3, 1, 64, 192, 191, 193, 2900, 8, 4300]),      # 45 x 4 tiles of 192 x 256
-    (1024, 256, 4, [1, 190, 2, 8300, 59]),                               # 45 x 1 tiles, four K ranges
+    (256, 1024, 1, [700, 3, 1, 64, 192, 191, 193, 2900, 8, 4300]),
+    (1024, 256, 4, [1, 190, 2, 8300, 59]),                               # four K ranges
     (256, 512, 1, [192 * 85 + 7]),                                       # one long utterance, ragged last tile
 ])
-def test_conv_gemm_big_tile(cin, n, ksplit, lens):
-    """the 192 x 256 / ring-of-three-stages kernel the frame-level FFN convs take (bf16, 9 taps), against torch's
-    fp32 conv of the same bf16-rounded operands, utterance by utterance"""
+def test_conv_gemm_frame_level_shapes(cin, n, ksplit, lens):
+    """frame-level FFN conv shapes (bf16, 9 taps, tens of M tiles, XCD-aware tile order) against torch's fp32 conv
+    of the same bf16-rounded operands, utterance by utterance"""
     taps, code, tdt = 9, hip.DTYPE_CODE["bf16"], torch.bfloat16
     g = torch.Generator().manual_seed(cin + n + ksplit)
     M = sum(lens)
@@ -138,9 +138,9 @@ def test_conv_gemm_big_tile(cin, n, ksplit, lens):
 
 def test_conv_gemm_ksplit_rule():
     ks = hip.load().fs2_conv_gemm_ksplit
-    assert ks(24400, 1024, 256, 9, 1) == 1          # frame-level first FFN conv: 512 big tiles
-    assert ks(24400, 256, 1024, 9, 1) == 2          # second: 128 tiles of 192 x 256 -> two K ranges, one per CU
-    assert ks(24400, 256, 1024, 9, 0) == 3          # fp32 stays on the 128 x 128 kernel
+    assert ks(24400, 1024, 256, 9, 1) == 1          # frame-level first FFN conv: 191 x 8 tiles
+    assert ks(24400, 256, 1024, 9, 1) == 3          # second: 191 x 2 tiles, long K -> three K ranges
+    assert ks(120, 256, 1024, 9, 1) > 1             # batch-1 decoding: a handful of tiles
     assert ks(0, 256, 256, 1, 1) == 1
     for M, N, C, t in [(120, 256, 1024, 9), (4000, 768, 256, 1), (3900, 256, 1024, 9), (700, 80, 256, 1)]:
         for code in (0, 1):
