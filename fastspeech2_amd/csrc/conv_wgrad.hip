@@ -376,6 +376,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     for (int o = tid; o < total; o += 256) dst[o] = accumulate ? dst[o] + tile[o] : tile[o];
 }
 
+// The same for NC % 4 == 0 (every layer of the model), with 16-byte loads and more of them in flight (the scalar
+// form is latency-bound at < 1 TB/s): a workgroup covers 256 positions; wave w sums taps w, w + 4, ... — lane l the
+// four positions 4 l .. 4 l + 3, all splits of a tap issued together; the [tap][256] block goes through LDS (rows
+// padded to 260 floats) to come out as 256 * taps consecutive floats.
+constexpr int WR_V4_POS = 256, WR_V4_LD = WR_V4_POS + 4, WR_V4_MAXK = 8;
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_v4_kernel(const float* __restrict__ part, float* __restrict__ grad,
+                                                                   int ksplit, int taps, long long NC, float scale,
+                                                                   int accumulate, const float* __restrict__ bias_part,
+                                                                   float* __restrict__ dbias, int N, int main_blocks) {
+    __shared__ __attribute__((aligned(16))) float tile[9 * WR_V4_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x >= main_blocks) {                  // trailing workgroups: the bias gradient
+        const long long n = (long long)(blockIdx.x - main_blocks) * 256 + tid;
+        if (dbias && n < N) {
+            float s = 0.f;
+            for (int k = 0; k < ksplit; ++k) s += bias_part[(size_t)k * N + n];
+            s *= scale;
+            dbias[n] = accumulate ? dbias[n] + s : s;
+        }
+        return;
+    }
+    const long long idx0 = (long long)blockIdx.x * WR_V4_POS;
+    const long long idx = idx0 + 4 * lane;
+    const size_t kstride = (size_t)taps * NC;
+    if (idx < NC) {
+        for (int t = wave; t < taps; t += 4) {
+            const float* src = part + (size_t)t * NC + idx;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < ksplit; k0 += WR_V4_MAXK) {
+                f32x4 v[WR_V4_MAXK];
+#pragma unroll
+                for (int j = 0; j < WR_V4_MAXK; ++j) {     // clamped address, predicated use: the loads go out together
+                    const int k = k0 + j < ksplit ? k0 + j : ksplit - 1;
+                    v[j] = *(const f32x4*)(src + (size_t)k * kstride);
+                }
+#pragma unroll
+                for (int j = 0; j < WR_V4_MAXK; ++j)
+                    if (k0 + j < ksplit) s += v[j];
+            }
+            *(f32x4*)(tile + t * WR_V4_LD + 4 * lane) = s * scale;
+        }
+    }
+    __syncthreads();
+    const long long left = NC - idx0;
+    const int total = (int)(left < WR_V4_POS ? left : WR_V4_POS) * taps;
+    float* dst = grad + idx0 * taps;
+    for (int o = tid; o < total; o += 256) {
+        const int pos = o / taps, t = o - pos * taps;
+        const float v = tile[t * WR_V4_LD + pos];
+        dst[o] = accumulate ? dst[o] + v : v;
+    }
+}
+
 }  // namespace fs2
 
 using namespace fs2;
@@ -443,8 +496,15 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
     } else {
         (void)hipMemsetAsync(workspace, 0, (size_t)fs2_conv_wgrad_workspace(N, Cin, taps, ksplit), stream);
     }
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((NC + 255) / 256 + (dbias ? (N + 255) / 256 : 0))), dim3(256), 0, stream,
-                       workspace, grad, ksplit, taps, NC, scale, accumulate, bias_part, dbias, N);
+    if ((NC & 3) == 0) {
+        const int main_blocks = (int)((NC + WR_V4_POS - 1) / WR_V4_POS);
+        hipLaunchKernelGGL(conv_wgrad_reduce_v4_kernel, dim3((unsigned)(main_blocks + (dbias ? (N + 255) / 256 : 0))), dim3(256),
+                           0, stream, workspace, grad, ksplit, taps, NC, scale,
+                           accumulate, bias_part, dbias, N, main_blocks);
+    } else {
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((NC + 255) / 256 + (dbias ? (N + 255) / 256 : 0))),
+                           dim3(256), 0, stream, workspace, grad, ksplit, taps, NC, scale, accumulate, bias_part, dbias, N);
+    }
     FS2_CHECK_LAUNCH("fs2_conv_wgrad(reduce)");
     return FS2_OK;
 }
