@@ -297,11 +297,8 @@ template <typename T, int DK>
 static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStream_t stream) {
     constexpr int QT = sizeof(T) == 2 ? 2 : 1;     // 32 (bf16) / 16 (f32) queries per wave
     constexpr int lds = 2 * 2 * AT_BK * DK * (int)sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attention_kernel<T, DK, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    fs2_allow_lds((const void*)attention_kernel<T, DK, QT>, lds, &lds_ok);
     dim3 grid((max_len + 64 * QT - 1) / (64 * QT), H, B);
     hipLaunchKernelGGL((attention_kernel<T, DK, QT>), grid, dim3(AT_THREADS), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_attention");

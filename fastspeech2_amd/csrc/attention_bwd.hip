@@ -352,12 +352,9 @@ template <typename T, int DK>
 static int launch_attention_bwd(const AttnBwdArgs& a, int B, int H, int max_len, hipStream_t stream) {
     constexpr int lds = 2 * 2 * AB_BT * DK * (int)sizeof(T);
     constexpr int lds_dkv = lds + 2 * 512;            // + lse / delta rows of both stages
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<T, DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<T, DK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dkv);
-        attr_set = true;
-    }
+    static unsigned long long ok_dq = 0, ok_dkv = 0;
+    fs2_allow_lds((const void*)attn_bwd_dq_kernel<T, DK>, lds, &ok_dq);
+    fs2_allow_lds((const void*)attn_bwd_dkv_kernel<T, DK>, lds_dkv, &ok_dkv);
     dim3 grid((max_len + AB_BT - 1) / AB_BT, H, B);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DK>), grid, dim3(AB_THREADS), lds, stream, a);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DK>), grid, dim3(AB_THREADS), lds_dkv, stream, a);

@@ -4,6 +4,7 @@
 // What autograd's backward of the reference modules computes (run/train_decode.py:94-97 calls
 // loss.backward() on network/fastspeech2.py:232-295) restated over the packed ragged layout.
 #include "common.h"
+#include "../../include/fs2_pack_desc.h"
 
 namespace fs2 {
 
@@ -356,6 +357,38 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
     }
 }
 
+// Many weights in one launch: workgroup b belongs to descriptor j with start[j] <= b < start[j + 1] (binary search);
+// the first half of a descriptor's workgroups writes the fwd operand, the second half the bwd operand.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const fs2_pack_desc* __restrict__ desc,
+                                                                   const int* __restrict__ start, int n) {
+    int lo = 0, hi = n;                       // invariant: start[lo] <= blockIdx.x < start[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)blockIdx.x >= start[mid]) lo = mid; else hi = mid;
+    }
+    const fs2_pack_desc d = desc[lo];
+    const int nb = (start[lo + 1] - start[lo]) >> 1;
+    int b = blockIdx.x - start[lo];
+    const int transposed = b >= nb;
+    b -= transposed ? nb : 0;
+    const long long idx = (long long)b * 256 + threadIdx.x;
+    if (idx >= (long long)d.N * d.C) return;
+    int nn, c;
+    if (transposed) { c = (int)(idx / d.N); nn = (int)(idx % d.N); } else { nn = (int)(idx / d.C); c = (int)(idx % d.C); }
+    const float* sp = d.src + ((size_t)nn * d.C + c) * d.k;
+    T* fwd = (T*)d.fwd;
+    T* bwd = (T*)d.bwd;
+    for (int t = 0; t < d.k; ++t) {
+        const T v = from_f32<T>(sp[t]);
+        if (transposed) {
+            if (bwd) bwd[(size_t)(d.k - 1 - t) * d.tap_stride_bwd + (size_t)c * d.ld_bwd + nn] = v;
+        } else {
+            if (fwd) fwd[(size_t)t * d.tap_stride_fwd + (size_t)nn * d.ld_fwd + c] = v;
+        }
+    }
+}
+
 }  // namespace fs2
 
 using namespace fs2;
@@ -515,5 +548,20 @@ extern "C" int fs2_pack_weight(const float* src, void* fwd, void* bwd, int N, in
                                (float*)bwd, N, C, k, ld_fwd, ld_bwd, tap_stride_fwd, tap_stride_bwd, tr);
     }
     FS2_CHECK_LAUNCH("fs2_pack_weight");
+    return FS2_OK;
+}
+
+// fs2_pack_weight for `n` weights in one launch.  desc and start live in DEVICE memory: desc[j] as in
+// include/fs2_pack_desc.h, start[0..n] the running sum of 2 * ceil(N_j * C_j / 256) (workgroups per weight);
+// total_blocks = start[n].
+extern "C" int fs2_pack_weights(const fs2_pack_desc* desc, const int* start, int n, int total_blocks, int dtype,
+                                hipStream_t stream) {
+    FS2_CHECK_ARG(desc && start && n > 0 && total_blocks > 0, "fs2_pack_weights: bad args");
+    FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_pack_weights: dtype=%d", dtype);
+    if (dtype == 1)
+        hipLaunchKernelGGL(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, stream, desc, start, n);
+    else
+        hipLaunchKernelGGL(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, stream, desc, start, n);
+    FS2_CHECK_LAUNCH("fs2_pack_weights");
     return FS2_OK;
 }

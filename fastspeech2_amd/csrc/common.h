@@ -114,6 +114,19 @@ static inline fs2::Dropout fs2_make_dropout(unsigned seed, unsigned stream, floa
     return d;
 }
 
+// ---- dynamic-LDS opt-in, once per (kernel instantiation, device) -----------------------------------
+// hipFuncSetAttribute acts on the current device's copy of the kernel, so a process that drives several GPUs has
+// to repeat it on each; `done` is the caller's static bit mask (one bit per device ordinal < 64).
+static inline void fs2_allow_lds(const void* kernel, int bytes, unsigned long long* done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(__atomic_load_n(done, __ATOMIC_RELAXED) & bit)) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+    }
+}
+
 // ---- error codes of the C ABI (include/fs2_hip.h) -----------------------------------------
 #define FS2_OK 0
 #define FS2_ERR_ARG (-1)

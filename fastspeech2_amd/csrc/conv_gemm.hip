@@ -443,12 +443,8 @@ template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int K
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
     constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    fs2_allow_lds((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>, lds, &lds_ok);
     const int grid_x = conv_gemm_plan_grid(a, BM, BN, sizeof(T));
     hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>), dim3(grid_x, a.ksplit),
                        dim3(128 * WM), lds, stream, a);
@@ -534,6 +530,7 @@ extern "C" int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype) 
     if (blocks >= 200 && blocks < 600 && nch * taps >= 64) {
         // narrow output, long K (second FFN conv at frame level): ~400 workgroups leave the CUs with one or two
         // resident each; three K ranges (~1200 workgroups, 3 per CU) measured 82 vs 89 us per launch
+        // (end to end, with the extra partial traffic of the LayerNorm kernels: 1 / 2 / 3 ranges within 1 %)
         return 3;
     }
     if (blocks >= 200 || nch * taps < 32) return 1;

@@ -464,17 +464,14 @@ extern "C" int fs2_conv_wgrad(const void* dY, const void* X, float* grad, float*
         if (!has_seg) a.seg = nullptr;
         const int tw = tw3 ? 3 : 1;
         const int lds = wgrad_stages(tw) * ((16 + (WG_KT + tw - 1 + 3) / 4) * 1024 + (has_seg ? 512 : 0));
-        static bool attr_set = false;
-        if (!attr_set) {
-            const int big = 3 * (33 * 1024 + 512);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-            attr_set = true;
-        }
+        static unsigned long long ok[6] = {0, 0, 0, 0, 0, 0};
+        const int big = 3 * (33 * 1024 + 512);
+        fs2_allow_lds((const void*)conv_wgrad_kernel<float, 1, false>, big, &ok[0]);
+        fs2_allow_lds((const void*)conv_wgrad_kernel<bf16_t, 1, false>, big, &ok[1]);
+        fs2_allow_lds((const void*)conv_wgrad_kernel<float, 1, true>, big, &ok[2]);
+        fs2_allow_lds((const void*)conv_wgrad_kernel<bf16_t, 1, true>, big, &ok[3]);
+        fs2_allow_lds((const void*)conv_wgrad_kernel<float, 3, true>, big, &ok[4]);
+        fs2_allow_lds((const void*)conv_wgrad_kernel<bf16_t, 3, true>, big, &ok[5]);
         dim3 grid(a.n_tiles * a.c_tiles * (tw3 ? taps / 3 : taps), ksplit);
         if (tw3) {
             if (dtype == 0)

@@ -47,6 +47,42 @@ class _Weight:
             call("fs2_pack_weight", ptr(p.data), hip.c_void_p(f), hip.c_void_p(b), self.n_each, self.C, self.k, self.C,
                  self.Np, self.N * self.C, self.C * self.Np, code, stream())
 
+    def descriptors(self):
+        """(src, fwd, bwd, N, C, k, ld_fwd, ld_bwd, 0, tap_stride_fwd, tap_stride_bwd) per parameter: fs2_pack_desc"""
+        esz = self.fwd.element_size()
+        return [(p.data.data_ptr(), self.fwd.data_ptr() + j * self.n_each * self.C * esz,
+                 self.bwd.data_ptr() + j * self.n_each * esz, self.n_each, self.C, self.k, self.C, self.Np, 0,
+                 self.N * self.C, self.C * self.Np) for j, p in enumerate(self.params)]
+
+
+PACK_DESC = np.dtype([("src", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"), ("N", "<i4"), ("C", "<i4"), ("k", "<i4"),
+                      ("ld_fwd", "<i4"), ("ld_bwd", "<i4"), ("reserved", "<i4"), ("ts_fwd", "<i8"), ("ts_bwd", "<i8")])
+assert PACK_DESC.itemsize == 64          # include/fs2_pack_desc.h
+
+
+class _PackGroup:
+    """The weights of one refresh group as one fs2_pack_weights launch; the device-side table is rebuilt when a
+    parameter's storage moved (model.to(), load_state_dict(assign=True), ...)."""
+
+    def __init__(self, weights: Sequence[_Weight], dev):
+        self.weights = list(weights)
+        self.dev = dev
+        self.key = None
+        self.table = self.start = None
+        self.n = self.blocks = 0
+
+    def launch(self, code):
+        key = tuple(p.data.data_ptr() for w in self.weights for p in w.params)
+        if key != self.key:
+            rows = [r for w in self.weights for r in w.descriptors()]
+            desc = np.array(rows, dtype=PACK_DESC)
+            start = np.zeros(len(rows) + 1, np.int32)
+            start[1:] = np.cumsum([2 * (-(-(r[3] * r[4]) // 256)) for r in rows])
+            self.table = torch.from_numpy(desc.view(np.uint8).copy()).to(self.dev)
+            self.start = torch.from_numpy(start).to(self.dev)
+            self.n, self.blocks, self.key = len(rows), int(start[-1]), key
+        call("fs2_pack_weights", ptr(self.table), ptr(self.start), self.n, self.blocks, code, stream())
+
 
 class TrainEngine:
     SITE_ENC_POS, SITE_DEC_POS = (2 << 16) + 1, (2 << 16) + 2
@@ -96,6 +132,7 @@ class TrainEngine:
         self.grad_finish: Optional[Callable[[], None]] = None     # called when every bucket has been announced
         self.profile = None
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)     # None: weight gradients on the main stream
+        self._pack_groups = None
         self._wgrad_pending = False
 
     # ------------------------------------------------------------------ set-up
@@ -350,9 +387,6 @@ class TrainEngine:
                 wc = self.P[p + "concat_linear.weight"].data
                 L["wc_x"].params[0].data.copy_(wc[:, :self.d])
                 L["wc_a"].params[0].data.copy_(wc[:, self.d:])
-            for k in ("wqkv", "wo", "w1", "w2", "wc_x", "wc_a"):
-                if k in L:
-                    L[k].pack(self.code)
 
     def refresh_weights(self):
         """Re-pack every GEMM operand from the current parameter values (once per step).  Two groups on a side
@@ -363,17 +397,19 @@ class TrainEngine:
         side = self.wgrad_stream if self.wgrad_stream is not None else main
         if side is not main:
             side.wait_stream(main)                 # the optimiser's update of the parameters
+        if self._pack_groups is None:
+            lw = lambda layers: [L[k] for L in layers for k in ("wqkv", "wo", "w1", "w2", "wc_x", "wc_a") if k in L]
+            self._pack_groups = (
+                _PackGroup(lw(self.enc_layers) + [c["w"] for c in self.dur_pred["convs"]], self.dev),
+                _PackGroup([c["w"] for pr in (self.pitch_pred, self.energy_pred) for c in pr["convs"]] +
+                           lw(self.dec_layers) + [self.w_out], self.dev))
         with torch.cuda.stream(side):
-            self._pack_layers(self.enc_layers, self.cfg["encoder_concat_after"])
-            for c in self.dur_pred["convs"]:
-                c["w"].pack(self.code)
+            self._pack_layers(self.enc_layers, self.cfg["encoder_concat_after"])      # bias concatenation, concat_after split
+            self._pack_groups[0].launch(self.code)
             ev_phone = torch.cuda.Event()
             ev_phone.record()
-            for pr in (self.pitch_pred, self.energy_pred):
-                for c in pr["convs"]:
-                    c["w"].pack(self.code)
             self._pack_layers(self.dec_layers, self.cfg["decoder_concat_after"])
-            self.w_out.pack(self.code)
+            self._pack_groups[1].launch(self.code)
             ev_frame = torch.cuda.Event()
             ev_frame.record()
         return ev_phone, ev_frame

@@ -19,6 +19,7 @@
 #define FS2_HIP_H
 
 #include <hip/hip_runtime_api.h>
+#include "fs2_pack_desc.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -256,6 +257,13 @@ int fs2_scale(const float* x, float a, float* out, long long n, hipStream_t stre
  * fwd[t][n][c] (fs2_conv_gemm) and bwd[k-1-t][c][n] (input gradient); either may be NULL. */
 int fs2_pack_weight(const float* src, void* fwd, void* bwd, int N, int C, int k, int ld_fwd, int ld_bwd,
                     long long tap_stride_fwd, long long tap_stride_bwd, int dtype, hipStream_t stream);
+
+/* fs2_pack_weight for n weights in ONE launch (a training step re-packs every GEMM operand after the optimiser
+ * update: ~55 parameters, two launches each otherwise).  desc [n] and start [n + 1] live in DEVICE memory:
+ * desc[j] = the arguments of fs2_pack_weight (fs2_pack_desc.h), start = running sum of
+ * 2 * ceil(N_j * C_j / 256), total_blocks = start[n]. */
+int fs2_pack_weights(const fs2_pack_desc* desc, const int* start, int n, int total_blocks, int dtype,
+                     hipStream_t stream);
 
 #ifdef __cplusplus
 }
