@@ -187,8 +187,20 @@ __global__ __launch_bounds__(1024) void colreduce_finish_kernel(const float* __r
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int w = blockIdx.x * 64 + tx;
     float s = 0.f;
-    if (w < W)
-        for (int b = ty; b < nblk; b += 16) s += part[(size_t)b * stride + w];
+    if (w < W) {
+        // eight independent loads per trip (clamped row, predicated add): the chain of one-at-a-time loads was
+        // what this kernel's ~10 us consisted of
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = ty; b < nblk; b += 128) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int bb = b + 16 * j;
+                const float v = part[(size_t)(bb < nblk ? bb : nblk - 1) * stride + w];
+                acc[j] += bb < nblk ? v : 0.f;
+            }
+        }
+        s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && w < W) {
