@@ -472,6 +472,10 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // does; git history: "experimental 192x256 big-tile kernel") read 0.7x the bytes through L2 but ran the decoder
     // convs in 148 / 149 us against 118 / 123 us here: 536 workgroups at one per CU take three rounds, and inside
     // a round the waves still spent a third of their time in the stage wait (SQ_WAIT_INST_ANY 36 %, MFMA busy 33 %).
+    // The same ring for the phone-level launches (one workgroup per CU, nothing else to hide the DMA latency; W ring of
+    // three + double-buffered X in this template) gave 37.9 vs 40.9 us alone and lost 3 % in the overlapped
+    // throughput loop (83 KB of LDS keeps the other streams' workgroups off the CU): those launches are bound by the
+    // read -> wait -> MFMA chain of a single wave per SIMD, not by the stage latency.  Not kept.
     // FS2_CONV_MT=2|3|4 forces a tile height (experiments).
     static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
     int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
