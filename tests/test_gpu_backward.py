@@ -55,6 +55,8 @@ def _conv_ref(x, w, lens, taps):
     (1, 256, 80, [257], 2),
     (5, 128, 24, [33, 31], 1),
     (3, 256, 384, [64, 64, 64], 7),      # more splits than token blocks
+    (9, 128, 256, [2000, 1, 777, 63], 2),  # 23 token blocks per workgroup: the stage ring wraps many times
+    (5, 64, 64, [900, 131], 1),          # one-tap-per-workgroup form with utterance bounds, 17 blocks in a row
 ])
 def test_conv_wgrad_and_dgrad(dtype, taps, cin, n, lens, ksplit):
     code = hip.DTYPE_CODE[dtype]
@@ -100,6 +102,35 @@ def test_conv_wgrad_and_dgrad(dtype, taps, cin, n, lens, ksplit):
         expx = 1.25 * xr.grad * (gate.to(tdt).double() > 0)
         err = (dx.cpu().double() - expx).abs().max().item()
         assert err <= (2e-5 if dtype == "fp32" else 2e-3) * max(1.0, expx.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pack_weights_batched_equals_one_by_one(dtype):
+    """fs2_pack_weights (one launch, descriptor table on the device) against fs2_pack_weight per parameter"""
+    import numpy as np
+    from fastspeech2_amd.train_engine import PACK_DESC
+    code = hip.DTYPE_CODE[dtype]
+    tdt = hip.TORCH_DTYPE[code]
+    g = torch.Generator().manual_seed(5)
+    shapes = [(24, 16, 9), (7, 40, 1), (64, 64, 3), (1, 8, 5), (300, 33, 1)]
+    rows, refs, outs = [], [], []
+    for n, c, k in shapes:
+        w = torch.randn(n, c, k, generator=g).to(DEV).contiguous()
+        ld_b = n + 3                                                     # padded bwd rows
+        f1, b1 = torch.zeros((k, n, c), device=DEV, dtype=tdt), torch.zeros((k, c, ld_b), device=DEV, dtype=tdt)
+        f2, b2 = torch.zeros_like(f1), torch.zeros_like(b1)
+        call("fs2_pack_weight", ptr(w), ptr(f1), ptr(b1), n, c, k, c, ld_b, n * c, c * ld_b, code, stream())
+        rows.append((w.data_ptr(), f2.data_ptr(), b2.data_ptr(), n, c, k, c, ld_b, 0, n * c, c * ld_b))
+        refs.append((w, f1, b1))
+        outs.append((f2, b2))
+    start = np.zeros(len(rows) + 1, np.int32)
+    start[1:] = np.cumsum([2 * (-(-(r[3] * r[4]) // 256)) for r in rows])
+    table = torch.from_numpy(np.array(rows, dtype=PACK_DESC).view(np.uint8).copy()).to(DEV)
+    start_d = torch.from_numpy(start).to(DEV)
+    call("fs2_pack_weights", ptr(table), ptr(start_d), len(rows), int(start[-1]), code, stream())
+    for (w, f1, b1), (f2, b2) in zip(refs, outs):
+        assert torch.equal(f1, f2) and torch.equal(b1, b2)
+        assert torch.equal(f2.float(), w.to(tdt).float().permute(2, 0, 1))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
