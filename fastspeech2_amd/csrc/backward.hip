@@ -8,7 +8,7 @@
 
 namespace fs2 {
 
-constexpr int LNB_MAXV = 4;          // float4 per lane -> C <= 1024
+constexpr int LNB_MAXV = 4;          // float4 per lane at most -> C <= 1024
 #ifndef FS2_LNB_ROWS
 #define FS2_LNB_ROWS 32
 #endif
@@ -18,7 +18,9 @@ constexpr int LNB_ROWS = FS2_LNB_ROWS;   // rows per workgroup (4 waves x LNB_RO
 //   xh = (x - mean) * rstd,  h = g * w,  dx = rstd * (h - mean(h) - xh * mean(h * xh))
 // (w == null: dx = g);  then dx += dres;  relu_gate: dx = x > 0 ? dx : 0 (x is a ReLU output).
 // Per-workgroup partial sums of d gamma = sum g * xh and d beta = sum g go to wb_part[blk][2][C].
-template <typename T>
+// NV = float4 per lane (C <= 256 NV); the dγ/dβ staging in LDS is sized to C (dynamic: 8 C floats), so that the
+// kernel's workgroups fit beside the 100 KB conv_wgrad workgroup that shares the CU during a training step.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ parts, int nparts,
                                                             long long part_stride, const float* __restrict__ w,
@@ -29,21 +31,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     // din: the forward applied dropout to this LayerNorm's OUTPUT (or, with w == null, to the tensor whose gradient
     // is summed here): the incoming gradient g is masked first.  dto: only the T copy of dx is masked — it is the
     // gradient of a dropped-out sub-layer output (residual + dropout(f(x))), while the fp32 dx flows to the residual.
-    __shared__ float red[4][2][LNB_MAXV * 256];
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cv = C >> 2;
-    f32x4 dgam[LNB_MAXV], dbet[LNB_MAXV];
+    f32x4 dgam[NV], dbet[NV];
 #pragma unroll
-    for (int k = 0; k < LNB_MAXV; ++k) dgam[k] = dbet[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NV; ++k) dgam[k] = dbet[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float invC = 1.0f / (float)C;
     for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
         const int row = blockIdx.x * LNB_ROWS + rr * 4 + wave;
         if (row >= M) break;
         const size_t roff = (size_t)row * C;
-        f32x4 xv[LNB_MAXV], gv[LNB_MAXV];
+        f32x4 xv[NV], gv[NV];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LNB_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int j = lane + k * 64;
             if (j < cv) {
                 f32x4 t = dy ? *(const f32x4*)(dy + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             mean = wave_sum(s) * invC;
             float q = 0.f;
 #pragma unroll
-            for (int k = 0; k < LNB_MAXV; ++k) {
+            for (int k = 0; k < NV; ++k) {
                 const int j = lane + k * 64;
                 if (j < cv) {
 #pragma unroll
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < LNB_MAXV; ++k) {
+            for (int k = 0; k < NV; ++k) {
                 const int j = lane + k * 64;
                 if (j < cv) {
                     const f32x4 ww = *(const f32x4*)(w + j * 4);
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             m2 = wave_sum(a2) * invC;
         }
 #pragma unroll
-        for (int k = 0; k < LNB_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int j = lane + k * 64;
             if (j < cv) {
                 f32x4 o = gv[k];
@@ -126,17 +128,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     if (!wb_part) return;
 #pragma unroll
-    for (int k = 0; k < LNB_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int j = lane + k * 64;
         if (j < cv) {
-            *(f32x4*)(&red[wave][0][j * 4]) = dgam[k];
-            *(f32x4*)(&red[wave][1][j * 4]) = dbet[k];
+            *(f32x4*)(red + (wave * 2 + 0) * C + j * 4) = dgam[k];
+            *(f32x4*)(red + (wave * 2 + 1) * C + j * 4) = dbet[k];
         }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
         const int which = idx / C, c = idx % C;
-        const float t = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+        const float* rp = red + which * C + c;
+        const float t = (rp[0] + rp[2 * C]) + (rp[4 * C] + rp[6 * C]);
         wb_part[(size_t)blockIdx.x * 2 * C + idx] = t;
     }
 }
@@ -436,12 +439,16 @@ extern "C" int fs2_layernorm_bwd(const float* x, const float* dy, const float* p
     }
     const int blocks = nblk(M, LNB_ROWS);
     float* part = w ? workspace : nullptr;
-    if (dtype == 1)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, stream, x, dy, parts, nparts,
-                           part_stride, w, dres, relu_gate, dx_f32, (bf16_t*)dx_t, part, M, C, eps, din, dto);
-    else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, stream, x, dy, parts, nparts,
-                           part_stride, w, dres, relu_gate, dx_f32, (float*)dx_t, part, M, C, eps, din, dto);
+    const size_t lds = w ? (size_t)8 * C * sizeof(float) : 0;
+#define FS2_LNB(TT, NVV)                                                                                             \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<TT, NVV>), dim3(blocks), dim3(256), lds, stream, x, dy, parts, nparts, \
+                       part_stride, w, dres, relu_gate, dx_f32, (TT*)dx_t, part, M, C, eps, din, dto)
+    if (dtype == 1) {
+        if (C <= 256) FS2_LNB(bf16_t, 1); else if (C <= 512) FS2_LNB(bf16_t, 2); else FS2_LNB(bf16_t, 4);
+    } else {
+        if (C <= 256) FS2_LNB(float, 1); else if (C <= 512) FS2_LNB(float, 2); else FS2_LNB(float, 4);
+    }
+#undef FS2_LNB
     FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
     if (w) {
         // part is [blocks][2][C]: one pass when db sits right behind dw, else two strided passes
