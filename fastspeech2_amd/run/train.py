@@ -87,6 +87,7 @@ class Updater:
         self.sync_nan_check = sync_nan_check
         self.skipped_steps = 0
         self._pending = []           # (event, pinned flag) of updates whose NaN flag has not been read yet
+        self._params = None          # list(model.parameters()), built once (the walk costs ~0.3 ms)
 
     def _base_optimizer(self):
         return getattr(self.optimizer, "optimizer", self.optimizer)
@@ -114,7 +115,9 @@ class Updater:
         if self.forward_count != self.accum_grad:
             return
         self.forward_count = 0
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+        if self._params is None:
+            self._params = list(self.model.parameters())
+        grad_norm = torch.nn.utils.clip_grad_norm_(self._params, self.grad_clip)
         self.last_grad_norm = grad_norm
         base = self._base_optimizer()
         on_device = isinstance(grad_norm, torch.Tensor) and grad_norm.is_cuda and bool(base.defaults.get("fused"))

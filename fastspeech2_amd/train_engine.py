@@ -133,6 +133,8 @@ class TrainEngine:
         self.profile = None
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)     # None: weight gradients on the main stream
         self._pack_groups = None
+        self._side_raw = self.wgrad_stream.cuda_stream           # raw hipStream_t of the side stream
+        self._ws_cache = {}
         self._wgrad_pending = False
 
     # ------------------------------------------------------------------ set-up
@@ -251,8 +253,15 @@ class TrainEngine:
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, device=self.dev, dtype=dtype or self.tdt)
 
-    def _ws(self, nbytes):
-        return torch.empty((max(int(nbytes), 16) + 3) // 4, device=self.dev, dtype=torch.float32)
+    def _ws(self, nbytes, raw_stream=None):
+        """Kernel scratch (split partials, per-workgroup sums).  One buffer per stream, grown on demand: the kernels
+        that use it run in order on that stream, each done with it before the next one starts."""
+        key = stream().value if raw_stream is None else raw_stream
+        n = (max(int(nbytes), 16) + 3) // 4
+        buf = self._ws_cache.get(key)
+        if buf is None or buf.numel() < n:
+            buf = self._ws_cache[key] = torch.empty(n, device=self.dev, dtype=torch.float32)
+        return buf
 
     def _ksplit(self, M, N, Cin, taps):
         return Engine._ksplit(M, N, Cin, taps, self.code)       # same split-K rule as the inference schedule
@@ -349,14 +358,18 @@ class TrainEngine:
             return
         # weight gradients are leaves of the backward: they run on a side stream, beside the input-gradient
         # chain on the main stream (ordered after the kernel that produced dy; joined before the buckets are used)
-        main, side = torch.cuda.current_stream(), self.wgrad_stream
+        side = self.wgrad_stream
         ev = torch.cuda.Event()
-        ev.record(main)
+        ev.record()
         side.wait_event(ev)
-        with torch.cuda.stream(side):
-            ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
-            call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, N,
-                 Cin, taps, N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
+        nbytes = hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks)
+        buf = self._ws_cache.get(self._side_raw)
+        if buf is None or buf.numel() * 4 < nbytes:
+            with torch.cuda.stream(side):          # (the caching allocator ties the block to the side stream)
+                buf = self._ws(nbytes, self._side_raw)
+        call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(buf), ptr(seg) if taps > 1 else None, M, N,
+             Cin, taps, N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0,
+             hip.c_void_p(self._side_raw))
         dy.record_stream(side)
         x.record_stream(side)
         self._wgrad_pending = True
