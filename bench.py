@@ -36,8 +36,8 @@ BATCH = 32
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--encoder-dtype", default=None, choices=[None, "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
