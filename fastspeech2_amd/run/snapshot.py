@@ -12,6 +12,8 @@ import torch
 
 def save_snapshot(path, model, optimizer, updater=None, save_func=torch.save):
     model = model.module if hasattr(model, "module") else model              # tools/snapshot.py:22-31
+    if hasattr(updater, "finalize"):
+        updater.finalize()            # outstanding device-side NaN flags: a skipped step gives back its schedule tick
     snap = {"trainer": {"iteration": getattr(updater, "iteration", 0), "forward_count": getattr(updater, "forward_count", 0)},
             "model": model.state_dict(), "optimizer": optimizer.state_dict()}
     out_dir = os.path.dirname(os.path.abspath(path))
