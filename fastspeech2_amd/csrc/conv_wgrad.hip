@@ -75,15 +75,25 @@ __device__ __forceinline__ void wg_lds_read_rows8(const void* row_r, int2 (&out)
 typedef unsigned wg_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
 #define WG_TR2(o0, o1, a) "ds_read_b64_tr_b16 %" #o0 ", %" #a " offset:%24\n\tds_read_b64_tr_b16 %" #o1 ", %" #a " offset:%25\n\t"
+// Issue only: the results may be used after wg_tr_wait<N>() on the same registers (N = younger LDS reads that may
+// still be outstanding; the LDS returns in order).  Both fragment steps of a block are issued back to back, so the
+// second step's reads are in flight under the first step's MFMAs.
 template <int OFF>
-__device__ __forceinline__ void wg_tr_read16(const unsigned (&ad)[8], bf16x8 (&out)[8]) {
-    wg_u2 r[16];
+__device__ __forceinline__ void wg_tr_issue16(const unsigned (&ad)[8], wg_u2 (&r)[16]) {
     asm volatile(WG_TR2(0, 1, 16) WG_TR2(2, 3, 17) WG_TR2(4, 5, 18) WG_TR2(6, 7, 19) WG_TR2(8, 9, 20) WG_TR2(10, 11, 21)
-                     WG_TR2(12, 13, 22) WG_TR2(14, 15, 23) "s_waitcnt lgkmcnt(0)"
+                     WG_TR2(12, 13, 22) WG_TR2(14, 15, 23) "; issued"
                  : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
                    "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
                  : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7]), "n"(OFF),
                    "n"(OFF + 16 * WG_ROWB)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wg_tr_wait(wg_u2 (&r)[16], bf16x8 (&out)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                   "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+                 : "n"(N)
                  : "memory");
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -183,12 +193,13 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
         const int slot = col >> 3, sub = (col & 7) * 2;
         return (unsigned)(img_off + row0 * WG_ROWB + (((slot + 2 * row0) & 15) << 4) + sub);
     };
-    unsigned foff[8];                                                // [0..WT): dY fragments, [4..4+WT): X fragments
+    unsigned ad[8];            // LDS addresses of this lane's fragments in the CURRENT stage: [0..4) dY, [4..8) X
     if constexpr (sizeof(T) == 2) {
+        const unsigned base = wg_lds_addr(smem);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            foff[k] = frag_off(0, wn * 64 + k * 16, 0);
-            foff[4 + k] = frag_off(WG_TILE_BYTES, wc * 64 + k * 16, wt);
+            ad[k] = base + frag_off(0, wn * 64 + k * 16, 0);
+            ad[4 + k] = base + frag_off(WG_TILE_BYTES, wc * 64 + k * 16, wt);
         }
     }
     auto load_frag = [&](const unsigned char* img, int ch0, int t0) __attribute__((always_inline)) -> frag_t {
@@ -201,7 +212,6 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
         }
         return f;
     };
-    const unsigned smem_addr = wg_lds_addr(smem);
 
     f32x4 acc[WT][WT];     // [c tile][n tile]: rows (4g + r) = channel c, column i = channel n
 #pragma unroll
@@ -228,8 +238,8 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
             const unsigned char* ys = smem + cur * STAGE_BYTES;
             const unsigned char* xs = ys + WG_TILE_BYTES;
             const int2* sl = (const int2*)(ys + SEGOFF);
-            const unsigned stage_addr = smem_addr + cur * STAGE_BYTES;
-            cur = cur + 1 == NST ? 0 : cur + 1;
+            const bool cur_was_last = cur + 1 == NST;
+            cur = cur_was_last ? 0 : cur + 1;
             fill = fill + 1 == NST ? 0 : fill + 1;
             const int mb = kb * WG_KT;
 
@@ -262,15 +272,20 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
                 }
             }
 
+            wg_u2 raw[2][16];
+            if constexpr (sizeof(T) == 2) {
+                wg_tr_issue16<0>(ad, raw[0]);
+                wg_tr_issue16<32 * WG_ROWB>(ad, raw[1]);
+                const int step = cur_was_last ? -(NST - 1) * STAGE_BYTES : STAGE_BYTES;      // to the next ring slot
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ad[k] += step;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 frag_t yf[WT], xf[WT];
                 if constexpr (sizeof(T) == 2) {
-                    unsigned ad[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) ad[k] = stage_addr + foff[k];
                     bf16x8 fr[8];
-                    if (ks == 0) wg_tr_read16<0>(ad, fr); else wg_tr_read16<32 * WG_ROWB>(ad, fr);
+                    if (ks == 0) wg_tr_wait<15>(raw[0], fr); else wg_tr_wait<0>(raw[1], fr);   // (lgkmcnt is 4 bits: 15 = all of step 0 + one)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         yf[k] = fr[k];
@@ -299,6 +314,7 @@ __global__ __launch_bounds__(256 * TW, TW == 1 ? 2 : TW) void conv_wgrad_kernel(
                 for (int ct = 0; ct < WT; ++ct)
 #pragma unroll
                     for (int nt = 0; nt < WT; ++nt) acc[ct][nt] = mma16(xf[ct], yf[nt], acc[ct][nt]);
+                __builtin_amdgcn_sched_barrier(0);     // keep this step's MFMAs above the next step's wait
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the refills past the end still target this workgroup's LDS
