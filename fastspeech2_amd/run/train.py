@@ -26,7 +26,12 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.cuda = engine.flat.is_cuda
-        self.comm = torch.cuda.Stream(device=engine.flat.device) if self.cuda else None
+        # The collectives are issued on the engine's weight-gradient stream when it has one: that stream already runs
+        # behind the compute stream, and one stream fewer matters — HIP multiplexes streams onto GPU_MAX_HW_QUEUES
+        # (4) hardware queues, and a stream that sits in an event wait stalls whatever shares its queue (a separate
+        # communication stream cost the step its compute / weight-gradient overlap: 12.5 vs 8.7 ms with one rank).
+        side = getattr(engine, "wgrad_stream", None)
+        self.comm = (side if side is not None else torch.cuda.Stream(device=engine.flat.device)) if self.cuda else None
         self.works: List = []
         engine.grad_ready = self.bucket_ready
         engine.grad_finish = self.finish
@@ -37,14 +42,15 @@ class GradReducer:
             return
         buf = self.engine.flat[lo:hi]
         if self.cuda:
-            # order the collective after the bucket's last gradient kernels: the compute stream and, when the
-            # engine runs its weight-gradient GEMMs beside it, that stream too — without joining the two
+            # order the collective after the bucket's last gradient kernels on every producer stream other than
+            # the one it is issued on — without joining the streams
             streams = self.engine.producer_streams() if hasattr(self.engine, "producer_streams") else \
                 [torch.cuda.current_stream()]
             for st in streams:
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self.comm.wait_event(ev)
+                if st != self.comm:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    self.comm.wait_event(ev)
             with torch.cuda.stream(self.comm):
                 buf.mul_(1.0 / self.world)
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
