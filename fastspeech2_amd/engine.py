@@ -16,7 +16,7 @@ import torch
 
 from . import hip
 from .trace import span
-from .hip import F32, BF16, call, ptr, stream
+from .hip import F32, call, ptr, stream
 
 LN_EPS = 1e-12  # network/utils.py:41
 
