@@ -476,6 +476,8 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // three + double-buffered X in this template) gave 37.9 vs 40.9 us alone and lost 3 % in the overlapped
     // throughput loop (83 KB of LDS keeps the other streams' workgroups off the CU): those launches are bound by the
     // read -> wait -> MFMA chain of a single wave per SIMD, not by the stage latency.  Not kept.
+    // And for the decoder convs: W ring of three (two steps ahead, counted waits) + single X image = 65 KB, two
+    // workgroups per CU: 87.7 vs 83.8 us per launch — three workgroups with one stage ahead hide more than two with two.
     // FS2_CONV_MT=2|3|4 forces a tile height (experiments).
     static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
     int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
