@@ -1,5 +1,6 @@
 """-m gpu: the training step (forward + backward HIP schedules behind `loss.backward()`) against the
 gradient goldens of the repaired reference and against the oracle's autograd on ragged batches."""
+import math
 import numpy as np
 import pytest
 import torch
@@ -212,3 +213,29 @@ def test_async_nan_guard_skips_the_update_and_takes_back_the_schedule_tick():
     up2 = Updater(model, grad_clip=1.0, optimizer=opt, device=DEV, sync_nan_check=True)
     up2.update(bad)
     assert up2.skipped_steps == 1 and opt._step == 2
+
+
+def test_train_driver_runs_evaluates_snapshots_and_resumes(tmp_path):
+    """fastspeech2_amd.run.train_decode.main: two epochs on a synthetic corpus, validation, snapshot, resume"""
+    import json
+    import os
+    from fastspeech2_amd.run import train_decode
+    out = str(tmp_path / "exp")
+    common = ["--outdir", out, "--synthetic", "24", "--adim", "64", "--aheads", "2", "--elayers", "1", "--dlayers", "1",
+              "--eunits", "128", "--dunits", "128", "--positionwise-layer-type", "conv1d",
+              "--positionwise-conv-kernel-size", "3", "--duration-predictor-chans", "64", "--postnet-layers", "0",
+              "--batch-bins", "60000", "--transformer-warmup-steps", "50", "--report-interval-iters", "2",
+              "--precision", "fp32", "--sortagrad", "1"]
+    args = train_decode.get_parser().parse_args(common + ["--epochs", "2"])
+    args.adim = int(args.adim)
+    s1 = train_decode.train(args)
+    assert s1["iterations"] >= 2 and s1["skipped_steps"] == 0
+    assert math.isfinite(s1["validation/main/loss"]) and math.isfinite(s1["main/loss"])
+    for f in ("model.json", "snapshot.ep.1", "snapshot.ep.2", "model.loss.best"):
+        assert os.path.isfile(os.path.join(out, f)), f
+    idim, odim, conf = json.load(open(os.path.join(out, "model.json")))
+    assert (idim, odim) == (80, 80) and conf["adim"] == 64
+    args2 = train_decode.get_parser().parse_args(common + ["--epochs", "3", "--resume", os.path.join(out, "snapshot.ep.2")])
+    s2 = train_decode.train(args2)
+    assert s2["iterations"] > s1["iterations"]                      # continued from the restored counters: one more epoch
+    assert s2["validation/main/loss"] < 1.5 * s1["validation/main/loss"]

@@ -183,3 +183,33 @@ def test_snapshot_roundtrip(tmp_path):
     assert torch.equal(m2.weight, m.weight) and o2._step == 1 and o2.warmup == 10 and up2.iteration == 7
     st, st2 = o.optimizer.state_dict()["state"], o2.optimizer.state_dict()["state"]
     assert torch.equal(st[0]["exp_avg"], st2[0]["exp_avg"])
+
+
+def test_train_driver_corpus_converter_and_batches(tmp_path):
+    """run/train_decode.py counterpart: npz corpus round trip, the json-style `utts`, bins batching, CustomConverter"""
+    from fastspeech2_amd.run.batchfy import make_batchset
+    from fastspeech2_amd.run.train_decode import CustomConverter, NpzCorpus, get_parser
+    c = NpzCorpus.synthetic(20, seed=3, idim=30, odim=8, mean_len=12)
+    path = str(tmp_path / "corpus.npz")
+    c.save(path)
+    c2 = NpzCorpus.load(path)
+    assert c2.utts == c.utts and sorted(c2.arrays) == sorted(c.arrays)
+    for u, e in c.utts.items():
+        assert e["input"][0]["shape"] == [int(c.arrays[u + "/dur"].sum()), 8]
+        assert len(e["output"][0]["tokenid"].split()) == e["output"][0]["shape"][0]
+    batches = make_batchset(c.utts, batch_bins=4000, shortest_first=True)
+    assert sorted(u for b in batches for u, _ in b) == sorted(c.utts)
+    out = CustomConverter()([c.load_batch(batches[0])])
+    B = len(batches[0])
+    assert out["xs"].shape[0] == B and out["ys"].shape[2] == 8 and out["ps"].shape[2] == 4 and out["es"].shape[2] == 1
+    assert out["ds"].sum(1).tolist() == out["olens"].tolist()                  # teacher-forced durations cover the frames
+    assert out["xs"].dtype == torch.long and out["ys"].dtype == torch.float32
+    for i, l in enumerate(out["olens"].tolist()):                              # stop-token labels (:136-138)
+        assert out["labels"][i, l - 1:].min() == 1.0 and (l == 1 or out["labels"][i, :l - 1].max() == 0.0)
+    bad = dict(c.arrays)
+    first = sorted(c.utts)[0]
+    bad[first + "/dur"] = bad[first + "/dur"] + 1
+    with pytest.raises(ValueError):
+        NpzCorpus(bad)
+    args = get_parser().parse_args(["--outdir", "x", "--synthetic", "4", "--adim", "64", "--positionwise-layer-type", "conv1d"])
+    assert args.adim == 64 and args.positionwise_layer_type == "conv1d" and args.elayers is None
