@@ -164,6 +164,73 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
     }
 }
 
+// LayerNorm(x) followed by the tiny head, without materialising the LayerNorm output: the last layer of the pitch /
+// energy predictors at frame level, where that fp32 matrix (M x 384) was written only to be read once by
+// rowdot_kernel.  Same arithmetic in the same order as add_layernorm_kernel + rowdot_kernel.  Inference only (the
+// training step keeps the LayerNorm output for the head's weight gradient).
+__global__ __launch_bounds__(256) void layernorm_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, const float* __restrict__ W,
+                                                               const float* __restrict__ hb, float* __restrict__ out, int M,
+                                                               int C, int NOUT, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int cv = C >> 2;
+    const size_t roff = (size_t)row * C;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            v[k] = *(const f32x4*)(x + roff + j * 4);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dlt = v[k][r] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            const f32x4 ww = *(const f32x4*)(w + j * 4);
+            const f32x4 bb = *(const f32x4*)(b + j * 4);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                if (h < NOUT) {
+                    const f32x4 wv = *(const f32x4*)(W + (size_t)h * C + j * 4);
+                    acc[h] += (o[0] * wv[0] + o[1] * wv[1]) + (o[2] * wv[2] + o[3] * wv[3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        if (h < NOUT) {
+            const float t = wave_sum(acc[h]);
+            if (lane == 0) out[(size_t)row * NOUT + h] = t + hb[h];
+        }
+    }
+}
+
 // a8: DurationPredictor.inference rounding — clamp(round(exp(x) - 1), min=0).long()
 // (network/variance_adaptor.py:135; torch.round = round-half-to-even = rintf)
 __global__ void duration_round_kernel(const float* __restrict__ logd, int* __restrict__ dur, int M) {
@@ -602,5 +669,19 @@ extern "C" int fs2_cast(const float* src, void* dst, long long n, int dtype, hip
     else
         hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, (float*)dst, n);
     FS2_CHECK_LAUNCH("fs2_cast");
+    return FS2_OK;
+}
+
+/* out[m, j] = LayerNorm(x[m, :]) . W[j, :] + hb[j]: fs2_layernorm + fs2_rowdot in one pass, the LayerNorm output is not
+ * stored (last layer + `linear` of the variance predictors at inference, network/variance_adaptor.py:107-115). */
+extern "C" int fs2_layernorm_rowdot(const float* x, const float* w, const float* b, const float* W, const float* hb,
+                                    float* out, int M, int C, int nout, float eps, hipStream_t stream) {
+    FS2_CHECK_ARG(x && w && b && W && hb && out, "fs2_layernorm_rowdot: null pointer");
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV && nout >= 1 && nout <= 8,
+                  "fs2_layernorm_rowdot: C=%d nout=%d unsupported", C, nout);
+    if (M <= 0) return FS2_OK;
+    hipLaunchKernelGGL(layernorm_rowdot_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, W, hb, out, M, C, nout,
+                       eps);
+    FS2_CHECK_LAUNCH("fs2_layernorm_rowdot");
     return FS2_OK;
 }

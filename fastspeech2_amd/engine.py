@@ -262,7 +262,7 @@ class Engine:
             r0 += L
         return outs
 
-    def _predict(self, pr: _Predictor, x_t, seg, M, cin):
+    def _predict(self, pr: _Predictor, x_t, seg, M, cin, fuse_head=False):
         cur, code = x_t, pr.code
         n = len(pr.convs)
         y32 = None
@@ -270,6 +270,12 @@ class Engine:
             y = self._gemm(cur, c["w"], c["b"], M, c["chans"], cin, c["taps"], code,
                            seg=seg if c["taps"] > 1 else None, relu=True, out_f32=True)
             last = j == n - 1
+            if last and fuse_head:
+                # last LayerNorm + head in one pass over the conv output (the LayerNorm output is not stored)
+                out = self._empty((M, pr.nout), dtype=torch.float32)
+                call("fs2_layernorm_rowdot", ptr(y), ptr(c["ln_w"]), ptr(c["ln_b"]), ptr(pr.lin_w), ptr(pr.lin_b), ptr(out),
+                     M, c["chans"], pr.nout, LN_EPS, stream())
+                return out
             y32, cur = self._ln(y, c["ln_w"], c["ln_b"], M, c["chans"], code, last, not last)
             cin = c["chans"]
         out = self._empty((M, pr.nout), dtype=torch.float32)
@@ -366,8 +372,8 @@ class Engine:
              ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
         if dc == F32:
             hs_lrt = hs_lr32
-        pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d)
-        energy = self._predict(self.energy_pred, hs_lrt, seg_f, Mf, d)
+        pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
+        energy = self._predict(self.energy_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
         p_in = pitch if ps is None else ps.to(dev, torch.float32).contiguous()
         e_in = energy if es is None else es.to(dev, torch.float32).contiguous()
         pscale = float(pitch_control) if ps is None else 1.0

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "fs2_scale": [_P, _F, _P, _L, _P],
     "fs2_pack_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _P],
     "fs2_pack_weights": [_P, _P, _I, _I, _I, _P],
+    "fs2_layernorm_rowdot": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
 }
 # workspace-size queries (return bytes as long long, no launch)
 _SIZE_QUERIES = {

@@ -102,6 +102,12 @@ int fs2_attention_dump(const void* qkv, float* atten, int row0, int len, int n_h
 int fs2_rowdot(const float* x, const float* W, const float* b, float* out, int M, int C, int nout,
                hipStream_t stream);
 
+/* out[m,j] = LayerNorm(x[m,:]) . W[j,:] + hb[j]: fs2_layernorm followed by fs2_rowdot in one pass, the LayerNorm output
+ * is not stored — the last LayerNorm + `linear` of the pitch / energy predictors at inference
+ * (network/variance_adaptor.py:107-115 with repair D5). */
+int fs2_layernorm_rowdot(const float* x, const float* w, const float* b, const float* W, const float* hb, float* out,
+                         int M, int C, int nout, float eps, hipStream_t stream);
+
 /* dur[m] = (int) clamp(round_half_even(exp(logd[m]) - 1), 0) — DurationPredictor.inference,
  * network/variance_adaptor.py:135. */
 int fs2_duration_round(const float* logd, int* dur, int M, hipStream_t stream);

@@ -218,6 +218,24 @@ def test_rowdot(nout, C):
     assert (out.cpu() - F.linear(x, W, b)).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("nout,C", [(4, 384), (1, 256), (2, 64)])
+def test_layernorm_rowdot_equals_the_two_kernels(nout, C):
+    g = torch.Generator().manual_seed(nout * 10 + C)
+    M = 1337
+    x = torch.randn(M, C, generator=g).to(DEV) * 3 + 0.5
+    w, b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    W, hb = (torch.randn(nout, C, generator=g) / math.sqrt(C)).to(DEV), torch.randn(nout, generator=g).to(DEV)
+    y = torch.empty_like(x)
+    ref = torch.empty((M, nout), device=DEV)
+    call("fs2_layernorm", ptr(x), ptr(w), ptr(b), ptr(y), None, M, C, 1e-12, 0, stream())
+    call("fs2_rowdot", ptr(y), ptr(W), ptr(hb), ptr(ref), M, C, nout, stream())
+    out = torch.full((M, nout), float("nan"), device=DEV)
+    call("fs2_layernorm_rowdot", ptr(x), ptr(w), ptr(b), ptr(W), ptr(hb), ptr(out), M, C, nout, 1e-12, stream())
+    assert (out - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    exp = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-12) @ W.double().t() + hb.double()
+    assert (out.double() - exp).abs().max().item() <= 1e-4 * max(1.0, exp.abs().max().item())
+
+
 def test_duration_round_matches_oracle():
     # values at and around the .5 boundaries: round-half-to-even, clamp at 0, negatives
     vals = [math.log(1.5), math.log(2.5), math.log(3.5), -3.0, 0.0, 2.0, 5.0, math.log(1.49999), math.log(7.67)]
