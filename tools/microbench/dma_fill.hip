@@ -19,17 +19,21 @@ template <int N> __device__ __forceinline__ void wait_barrier() {
 // PW: instructions per wave per stage; AHEAD: stages in flight; a stage = NWAVES * PW KiB
 template <int SHAPE, int PW, int AHEAD>
 __global__ __launch_bounds__(1024) void dma_fill_kernel(const unsigned char* __restrict__ src, size_t region, int stride,
-                                                       int iters, int* sink) {
+                                                       int iters, int* sink, int share, int phase) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int stage_bytes = nwaves * PW * 1024;
     constexpr int NST = AHEAD + 1;
-    const unsigned char* base = src + (size_t)blockIdx.x * region;       // every workgroup streams its own region
+    // share == 1: every workgroup streams its own region.  share > 1: `share` workgroups of the SAME XCD (ids are dealt
+    // round-robin to the 8 XCDs) walk one region together; phase != 0 starts each of them `phase` iterations apart.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const unsigned char* base = src + (size_t)((slot / share) * 8 + xcd) * region;
+    const int it0 = (slot % share) * phase;
     auto issue = [&](int it, int slot) __attribute__((always_inline)) {
         // the tile of iteration `it`: rows of `stride` bytes; piece p covers 1 KiB of it
-        const size_t tile_off = ((size_t)it * stage_bytes) % region;
+        const size_t tile_off = ((size_t)(it + it0) * stage_bytes) % region;
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
             const int p = wave * PW + q;
@@ -56,12 +60,12 @@ __global__ __launch_bounds__(1024) void dma_fill_kernel(const unsigned char* __r
 
 template <int SHAPE, int PW, int AHEAD>
 static void run(const char* name, const unsigned char* src, size_t total, int wgs, int threads, int stride, int* sink,
-                double clock_ghz) {
+                double clock_ghz, int share = 1, int phase = 0) {
     const int nwaves = threads / 64;
     const int stage = nwaves * PW * 1024;
     const int lds = (AHEAD + 1) * stage;
     if (lds > 160 * 1024) return;
-    const size_t region = (total / wgs) & ~(size_t)4095;
+    const size_t region = (total / (wgs / share)) & ~(size_t)4095;
     const int iters = 400;
     hipFuncSetAttribute((const void*)dma_fill_kernel<SHAPE, PW, AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
@@ -69,7 +73,7 @@ static void run(const char* name, const unsigned char* src, size_t total, int wg
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((dma_fill_kernel<SHAPE, PW, AHEAD>), dim3(wgs), dim3(threads), lds, 0, src, region, stride, iters, sink);
+        hipLaunchKernelGGL((dma_fill_kernel<SHAPE, PW, AHEAD>), dim3(wgs), dim3(threads), lds, 0, src, region, stride, iters, sink, share, phase);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -78,6 +82,7 @@ static void run(const char* name, const unsigned char* src, size_t total, int wg
     const double bytes = (double)wgs * iters * stage;
     const double tbs = bytes / (best * 1e-3) / 1e12;
     const int wg_per_cu = (wgs + 255) / 256;
+    if (share > 1) printf("[share %2d phase %d] ", share, phase);
     printf("%-34s wgs %4d x %4d thr, stage %3d KB, in flight/WG %3d KB, LDS %3d KB: %6.2f TB/s = %5.1f B/clk/CU (@%.1f GHz)\n", name,
            wgs, threads, stage / 1024, AHEAD * stage / 1024, lds / 1024, tbs, tbs * 1e12 / 256 / (clock_ghz * 1e9), clock_ghz);
     (void)wg_per_cu;
@@ -99,6 +104,13 @@ int main(int argc, char** argv) {
     run<0, 3, 2>("contiguous, 12 waves, 2 ahead", src, total, 256, 768, 0, sink, ghz);
     run<2, 3, 2>("4x256B @2048B, 12 waves, 2 ahead", src, total, 256, 768, 2048, sink, ghz);
     run<2, 3, 3>("4x256B @2048B, 12 waves, 3 ahead", src, total, 256, 768, 2048, sink, ghz);
+    // the same bytes requested by several workgroups of one XCD at the same time (what the W tiles of a GEMM see)
+    for (int share : {1, 2, 4, 8, 32}) {
+        run<0, 4, 1>("contiguous, 3 WG/CU, 1 ahead", src, total, 768, 256, 0, sink, ghz, share, 0);
+        if (share > 1) run<0, 4, 1>("contiguous, 3 WG/CU, 1 ahead", src, total, 768, 256, 0, sink, ghz, share, 1);
+        if (share > 1) run<0, 4, 1>("contiguous, 3 WG/CU, 1 ahead", src, total, 768, 256, 0, sink, ghz, share, 3);
+        run<0, 3, 2>("contiguous, 12 waves, 2 ahead", src, total, 256, 768, 0, sink, ghz, share, 0);
+    }
     run<0, 8, 2>("contiguous, 4 waves x 8, 2 ahead", src, total, 256, 256, 0, sink, ghz);
     run<0, 8, 3>("contiguous, 4 waves x 8, 3 ahead", src, total, 256, 256, 0, sink, ghz);
     hipFree(src); hipFree(sink);
