@@ -29,6 +29,7 @@ struct AttnArgs {
     float scale_log2e;   // log2(e) / sqrt(dk)
     float* lse;          // [H][M] or null: log2-domain log-sum-exp of the scaled scores (saved for the backward)
     int M;
+    PairOrder order;     // XCD-aware workgroup order (common.h)
     Dropout drop;        // training: dropout of the probabilities (network/encoder.py:86); site = drop.stream + head
 };
 
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // stage s: K image at smem + s * 2 * TILE_BYTES, V image right behind it
 
-    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+    int b, h, qblk;
+    if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
     const int r0 = a.cu[b];
     const int len = a.cu[b + 1] - r0;
     if (qblk * BQ >= len) return;
@@ -299,8 +301,10 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
     constexpr int lds = 2 * 2 * AT_BK * DK * (int)sizeof(T);
     static unsigned long long lds_ok = 0;
     fs2_allow_lds((const void*)attention_kernel<T, DK, QT>, lds, &lds_ok);
-    dim3 grid((max_len + 64 * QT - 1) / (64 * QT), H, B);
-    hipLaunchKernelGGL((attention_kernel<T, DK, QT>), grid, dim3(AT_THREADS), lds, stream, a);
+    static const int xcd_on = getenv("FS2_ATTN_XCD") ? atoi(getenv("FS2_ATTN_XCD")) : 1;   // 0: plain grid (A/B runs)
+    AttnArgs aa = a;
+    const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 64 * QT - 1) / (64 * QT), H, B, xcd_on != 0);
+    hipLaunchKernelGGL((attention_kernel<T, DK, QT>), grid, dim3(AT_THREADS), lds, stream, aa);
     FS2_CHECK_LAUNCH("fs2_attention");
     return FS2_OK;
 }

@@ -34,6 +34,7 @@ struct AttnBwdArgs {
     int ld, ldo, d, M;
     float scale_log2e;   // log2(e) / sqrt(dk)
     float scale;         // 1 / sqrt(dk)
+    PairOrder order;     // XCD-aware workgroup order (common.h)
     Dropout drop;        // the forward's probability dropout (site = drop.stream + head), recomputed here
 };
 
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dq_kernel(AttnBwdArgs 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // stage s: K image (rotation 2) at smem + s * 2 * TILE, V image (rotation 1) behind it
 
-    const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+    int b, h, qblk;
+    if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
     const int r0 = a.cu[b];
     const int len = a.cu[b + 1] - r0;
     if (qblk * AB_BT >= len) return;
@@ -240,7 +242,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
     // loop would make hipcc drain the prefetch (vmcnt(0)) at every use.
     constexpr int STAGE = 2 * TILE + 512;
 
-    const int b = blockIdx.z, h = blockIdx.y, kblk = blockIdx.x;
+    int b, h, kblk;
+    if (!fs2_pair_order_decode(a.order, b, h, kblk)) return;
     const int r0 = a.cu[b];
     const int len = a.cu[b + 1] - r0;
     if (kblk * AB_BT >= len) return;
@@ -355,9 +358,11 @@ static int launch_attention_bwd(const AttnBwdArgs& a, int B, int H, int max_len,
     static unsigned long long ok_dq = 0, ok_dkv = 0;
     fs2_allow_lds((const void*)attn_bwd_dq_kernel<T, DK>, lds, &ok_dq);
     fs2_allow_lds((const void*)attn_bwd_dkv_kernel<T, DK>, lds_dkv, &ok_dkv);
-    dim3 grid((max_len + AB_BT - 1) / AB_BT, H, B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DK>), grid, dim3(AB_THREADS), lds, stream, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DK>), grid, dim3(AB_THREADS), lds_dkv, stream, a);
+    static const int xcd_on = getenv("FS2_ATTN_XCD") ? atoi(getenv("FS2_ATTN_XCD")) : 1;   // 0: plain grid (A/B runs)
+    AttnBwdArgs aa = a;
+    const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + AB_BT - 1) / AB_BT, H, B, xcd_on != 0);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DK>), grid, dim3(AB_THREADS), lds, stream, aa);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DK>), grid, dim3(AB_THREADS), lds_dkv, stream, aa);
     FS2_CHECK_LAUNCH("fs2_attention_bwd");
     return FS2_OK;
 }

@@ -127,6 +127,34 @@ static inline void fs2_allow_lds(const void* kernel, int bytes, unsigned long lo
     }
 }
 
+// ---- XCD-aware order of (block, head, utterance) grids ----------------------------------------------
+// Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  All blocks of one (utterance, head) pair
+// read the same K/V (or Q/dO) rows; with the plain (block, head, utterance) grid they land on as many XCDs as the pair
+// has blocks and every one of those L2s fetches the rows.  In this order pair p lives on XCD p % 8: the grid is 1-D,
+// id -> (xcd = id & 7, slot = id >> 3), pair = xcd + 8 * (slot / nblk), block = slot % nblk.
+struct PairOrder {
+    int nblk, pairs, H;      // pairs == 0: plain grid
+};
+static inline dim3 fs2_pair_order_grid(PairOrder& o, int nblk, int H, int B, bool on) {
+    o.nblk = nblk; o.H = H; o.pairs = 0;
+    if (!on || nblk < 2 || B * H < 8) return dim3(nblk, H, B);
+    o.pairs = B * H;
+    return dim3(8 * nblk * ((B * H + 7) / 8), 1, 1);
+}
+// false: this workgroup has no work (padding of the 1-D grid)
+__device__ __forceinline__ bool fs2_pair_order_decode(const PairOrder& o, int& b, int& h, int& blk) {
+    b = blockIdx.z; h = blockIdx.y; blk = blockIdx.x;
+    if (o.pairs > 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int pair = xcd + 8 * (slot / o.nblk);
+        if (pair >= o.pairs) return false;
+        blk = slot % o.nblk;
+        b = pair / o.H;
+        h = pair % o.H;
+    }
+    return true;
+}
+
 // ---- error codes of the C ABI (include/fs2_hip.h) -----------------------------------------
 #define FS2_OK 0
 #define FS2_ERR_ARG (-1)
