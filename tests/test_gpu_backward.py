@@ -266,7 +266,8 @@ def test_lr_scatter_embed_bwd_loss_grad():
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("h,dk,lens", [(2, 32, [5, 70, 1]), (2, 64, [130, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 129])])
+@pytest.mark.parametrize("h,dk,lens", [(2, 32, [5, 70, 1]), (2, 64, [130, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 129]),
+                                       (2, 64, [130, 64, 257, 1, 90])])   # 10 pairs: XCD-aware order with a padded grid
 def test_attention_fwd_lse_and_bwd(dtype, h, dk, lens):
     code = hip.DTYPE_CODE[dtype]
     tdt = hip.TORCH_DTYPE[code]
