@@ -495,7 +495,10 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // workgroups per CU: 87.7 vs 83.8 us per launch — three workgroups with one stage ahead hide more than two with two.
     // FS2_CONV_MT=2|3|4 forces a tile height (experiments).
     static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
-    int best = (a.N <= 256 && big_blocks < 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
+    // (only while the 96-row tiling itself still fits one round of 768 resident workgroups: M = 21000 with two K
+    // ranges is 660 tiles of 128 rows but 876 of 96, whose short second round cost 120 vs 105 us)
+    const long blocks96 = (long)((a.M + 95) / 96) * ((a.N + 127) / 128) * a.ksplit;
+    int best = (a.N <= 256 && big_blocks < 768 && blocks96 <= 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
     if (forced) best = forced;
     if (a.taps == 9) {      // the FFN convs: own symbol, compile-time tap count
         if (best == 3) return launch_conv_gemm<T, 3, 4, 2, 1, false, 3, 9>(a, stream);
@@ -543,24 +546,52 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
 }
 
 // Split-K factor the launch schedules use for a GEMM whose output is summed by an add + LayerNorm kernel
-// (fs2_add_layernorm `parts`): 1 unless the plain tiling would leave most CUs idle.
+// (fs2_add_layernorm `parts`).  Short K: 1.  Long K (>= 32 steps of one (chunk, tap) each; in practice the narrow
+// second FFN conv, N = 256, K = 9 x 1024): the factor with the lowest modelled time.  The model is fitted to
+// `tools/ks_sweep.py` on MI355X (bf16, N = 256, K = 9216, us per launch; * = chosen):
+//        M     ks=1     2      3      4      6      8
+//     3072     69.3   43.9   34.9   30.0   30.7*  26.9
+//     6144     78.3   49.6   45.2   39.6*  39.6   42.3
+//     9216     91.8   66.7   56.1*  52.5   54.8   60.9
+//    12288     92.1   69.8   64.4*  65.2   72.9   74.3
+//    18432    122.5   90.8*  97.9   97.8   97.7  108.4
+//    25603    152.7  145.8  123.7* 132.8  131.0  147.2
+//    40000    226.0  179.1* 183.6  187.5  198.2  224.1
+// (a later sweep over 810 ... 60000 tokens: the chosen factor is within 5 % of the best one everywhere.)
+// The table is reproduced within ~10 % by  time = (K steps / ks + 10) x step(w),  w = 128-row tiles x ks
+// workgroups, with ONE smooth step time: step(w) = max(0.75, 0.35 + w / 640) us for the 128 x 128 kernel (latency
+// floor + throughput term; no visible round quantisation except a short tail just past a full round of 768, +12 %)
+// and 0.42 + w64 / 3400 us for the 64 x 64 tiles the dispatch uses below 200 workgroups.  Every extra partial also
+// costs its fp32 read in the LayerNorm kernel (4.5 TB/s).  Unconstrained optimum: ks* = sqrt(3226 / tiles).
+static double conv_gemm_split_cost(int M, int N, int ksteps, long blocks, int ks) {
+    const double steps = (double)ksteps / ks + 10.0;
+    const double w = (double)blocks * ks;
+    double step;
+    if (w < 200.0) {
+        step = 0.42 + (double)((M + 63) / 64) * ((N + 63) / 64) * ks / 3400.0;
+    } else {
+        step = 0.35 + w / 640.0;
+        step = step < 0.75 ? 0.75 : step;
+        const double rem = w - 768.0 * (int)(w / 768.0);
+        if (w > 768.0 && rem > 0.0 && rem < 0.12 * 768.0) step *= 1.12;
+    }
+    return steps * step + (ks - 1) * ((double)M * N * 4.0 / 4.5e6);
+}
+
 extern "C" int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype) {
     const int nch = (Cin + (dtype == 1 ? 64 : 32) - 1) / (dtype == 1 ? 64 : 32);
-    if (M <= 0) return 1;
+    if (M <= 0 || nch * taps < 32) return 1;
     const long blocks = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (blocks >= 200 && blocks < 600 && nch * taps >= 64) {
-        // narrow output, long K (second FFN conv at frame level): ~400 workgroups leave the CUs with one or two
-        // resident each; three K ranges (~1200 workgroups, 3 per CU) measured 82 vs 89 us per launch
-        // (end to end, with the extra partial traffic of the LayerNorm kernels: 1 / 2 / 3 ranges within 1 %)
-        return 3;
+    static const int cand[6] = {1, 2, 3, 4, 6, 8};
+    int best = 1;
+    double best_cost = 0.0;
+    for (int q = 0; q < 6; ++q) {
+        const int ks = cand[q];
+        if (ks > nch || (ks > 1 && (nch / ks) * taps < 8)) break;
+        const double c = conv_gemm_split_cost(M, N, nch * taps, blocks, ks);
+        if (q == 0 || c < best_cost) { best = ks; best_cost = c; }
     }
-    if (blocks >= 200 || nch * taps < 32) return 1;
-    int ks = (int)(256 / blocks);
-    ks = ks > 8 ? 8 : ks;
-    ks = ks > nch ? nch : ks;
-    ks = ks < 1 ? 1 : ks;
-    while (ks > 1 && (nch / ks) * taps < 8) --ks;
-    return ks;
+    return best;
 }
 
 extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out,

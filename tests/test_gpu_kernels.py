@@ -139,7 +139,10 @@ def test_conv_gemm_frame_level_shapes(cin, n, ksplit, lens):
 def test_conv_gemm_ksplit_rule():
     ks = hip.load().fs2_conv_gemm_ksplit
     assert ks(24400, 1024, 256, 9, 1) == 1          # frame-level first FFN conv: 191 x 8 tiles
-    assert ks(24400, 256, 1024, 9, 1) == 3          # second: 191 x 2 tiles, long K -> three K ranges
+    assert ks(25603, 256, 1024, 9, 1) == 3          # second (bench batch): 201 x 2 tiles, long K -> three K ranges
+    assert ks(24400, 256, 1024, 9, 1) == 2          # 191 x 2 tiles: two ranges fill one round of 768 exactly
+    assert ks(12288, 256, 1024, 9, 1) in (3, 4)     # mid-size batches used to fall to 64 x 64 tiles unsplit
+    assert ks(4000, 256, 256, 1, 1) == 1            # short K: never split
     assert ks(120, 256, 1024, 9, 1) > 1             # batch-1 decoding: a handful of tiles
     assert ks(0, 256, 256, 1, 1) == 1
     for M, N, C, t in [(120, 256, 1024, 9), (4000, 768, 256, 1), (3900, 256, 1024, 9), (700, 80, 256, 1)]:
