@@ -499,6 +499,16 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // ranges is 660 tiles of 128 rows but 876 of 96, whose short second round cost 120 vs 105 us)
     const long blocks96 = (long)((a.M + 95) / 96) * ((a.N + 127) / 128) * a.ksplit;
     int best = (a.N <= 256 && big_blocks < 768 && blocks96 <= 768 && a.Cin * a.taps >= 2048) ? 3 : 4;
+    // Wide outputs (no split-K: ReLU epilogue) that fill less than about one round of 768 tiles of 128 rows: lower tiles
+    // give the CUs more workgroups to hide the stage latency with.  First FFN conv (N = 1024, K = 2304) alone, us per
+    // launch with 128 / 96 / 64 rows: M = 3767 (240 tiles): 36.9 / 36.8 / 31.8; 6144 (384): 45.6 / 39.1 / 38.4;
+    // 9216 (576): 53.7 / 48.6 / 60.5; 12383 (776): 72.7 / 70.5 / 79.4; from 15000 (944) up 128 rows win or tie.
+    static const int low_tiles = getenv("FS2_CONV_LOWTILES") ? atoi(getenv("FS2_CONV_LOWTILES")) : 1;   // 0: off (A/B runs)
+    if (low_tiles && a.ksplit == 1 && a.N > 256 && a.Cin * a.taps >= 1024) {
+        // (64 rows below 320 tiles: -14 % for that launch alone, but in the bench's overlapped mode, where the phone-level
+        // convs run beside the frame-level ones, the step got 1 % slower; not used)
+        if (big_blocks >= 320 && big_blocks < 800) best = 3;
+    }
     if (forced) best = forced;
     if (a.taps == 9) {      // the FFN convs: own symbol, compile-time tap count
         if (best == 3) return launch_conv_gemm<T, 3, 4, 2, 1, false, 3, 9>(a, stream);
