@@ -507,7 +507,9 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (low_tiles && a.ksplit == 1 && a.N > 256 && a.Cin * a.taps >= 1024) {
         // (64 rows below 320 tiles: -14 % for that launch alone, but in the bench's overlapped mode, where the phone-level
         // convs run beside the frame-level ones, the step got 1 % slower; not used)
-        if (big_blocks >= 320 && big_blocks < 800) best = 3;
+        // (and, as above, only while the 96-row tiling fits one round: 27 k x 384 x 1536 is 636 tiles of 128 rows but 846
+        // of 96, 72 vs 58 us)
+        if (big_blocks >= 320 && blocks96 <= 768) best = 3;
     }
     if (forced) best = forced;
     if (a.taps == 9) {      // the FFN convs: own symbol, compile-time tap count
