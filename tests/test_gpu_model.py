@@ -177,6 +177,46 @@ def test_full_size_properties_bf16():
             assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= BF16_MEL_TOL
 
 
+@pytest.mark.parametrize("precision,tol,flips", [("bf16", BF16_MEL_TOL, 0.02), ("fp32", FP32_MEL_TOL, 0.001)])
+def test_sub_batches_agree_with_the_full_batch(precision, tol, flips):
+    """BASELINE dims: the 32-utterance batch against the same utterances in groups of 4 / 8 / 16.  The token counts of the
+    groups (≈3 k / 6 k / 13 k frames) make the launch rules pick other split-K factors and tile heights
+    (fs2_conv_gemm_ksplit's cost model, 96-row tiles), i.e. other fp32 summation orders.  A duration is
+    round(exp(x) - 1), so a last-bit difference in x can flip one that sits on a rounding edge: at most `flips` of the
+    phones may differ, by one frame; utterances whose durations all agree must agree in the mel to the precision's
+    tolerance (an utterance with a flipped duration has shifted frames and is not compared)."""
+    from fastspeech2_amd import synth
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = synth.synth_state_dict(80, 80, 1234, dur_bias=float(np.log(7.67)), dur_w_scale=0.15, **kw)
+    model = FeedForwardTransformer(80, 80, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval().cuda().set_precision(precision)
+    xs = [torch.from_numpy(x) for x in synth.synth_utterances(32, 0)]
+    full = model.infer_batch(xs)
+    dur = full["packed"]["durations"].cpu().numpy()
+    cu_p = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    compared = phones = differing = 0
+    for group in (4, 8, 16):
+        for g0 in range(0, 32, group):
+            part = model.infer_batch(xs[g0:g0 + group])
+            pd = part["packed"]["durations"].cpu().numpy()
+            cu_q = np.concatenate([[0], np.cumsum([len(x) for x in xs[g0:g0 + group]])])
+            for j in range(group):
+                b = g0 + j
+                delta = pd[cu_q[j]:cu_q[j + 1]].astype(np.int64) - dur[cu_p[b]:cu_p[b + 1]].astype(np.int64)
+                phones += delta.size
+                differing += int((delta != 0).sum())
+                assert np.abs(delta).max() <= 1
+                if (delta != 0).any():
+                    continue
+                T = full["packed"]["olens"][b]
+                assert part["packed"]["olens"][j] == T
+                assert (part["mel"][j, :T] - full["mel"][b, :T]).abs().max().item() <= tol, (group, b)
+                compared += 1
+    assert differing <= flips * phones, (differing, phones)
+    assert compared >= (90 if precision == "fp32" else 24), compared
+
+
 def test_decode_entry_point():
     """run/fastspeech_decode.py:decode counterpart: eval+no_grad, controls, 8 fields, restores train()."""
     from argparse import Namespace
