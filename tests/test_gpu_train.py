@@ -254,7 +254,8 @@ def test_train_driver_runs_evaluates_snapshots_and_resumes(tmp_path):
     assert math.isfinite(s1["validation/main/loss"]) and math.isfinite(s1["main/loss"])
     for f in ("model.json", "snapshot.ep.1", "snapshot.ep.2", "model.loss.best"):
         assert os.path.isfile(os.path.join(out, f)), f
-    idim, odim, conf = json.load(open(os.path.join(out, "model.json")))
+    with open(os.path.join(out, "model.json")) as fh:
+        idim, odim, conf = json.load(fh)
     assert (idim, odim) == (80, 80) and conf["adim"] == 64
     args2 = train_decode.get_parser().parse_args(common + ["--epochs", "3", "--resume", os.path.join(out, "snapshot.ep.2")])
     s2 = train_decode.train(args2)
