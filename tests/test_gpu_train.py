@@ -151,9 +151,8 @@ def test_two_process_data_parallel_step(tmp_path):
     """Two data-parallel ranks (two processes on this GPU, gloo transport standing in for RCCL) with the bucketed
     reducer hooked into the backward: both end with the mean of the two single-rank gradients.
 
-    Known issue: about one run in fifteen of the whole GPU suite — so far only as the first GPU command on a fresh box,
-    never in 10 repeats of this test or 4 of the suite on a warm one — the two ranks stopped making progress after the
-    gloo rendezvous and ran into the 110 s limit (cause not found; the ranks now print their stage on stderr).  Both
+    Known issue: once in about 25 runs of the whole GPU suite the two ranks stopped making progress after the gloo
+    rendezvous and ran into the 110 s limit (cause not found; the ranks print their stage on stderr).  Both
     are then killed and the pair is started ONCE more; a second stall fails the test."""
     import os
     import socket
