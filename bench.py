@@ -141,9 +141,8 @@ def main():
     fence()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0      # this rank's K steps; the job time is the MAX over ranks (below)
-    fence()                                 # closing barrier: not part of any rank's steps (an RCCL barrier costs ~1 ms)
+    fence()
+    elapsed = time.perf_counter() - t0
     frames = float(sum(out["olens"]))
     flops = synth.algorithmic_flops(ilens, out["olens"])
     stats = torch.tensor([elapsed, frames, flops], dtype=torch.float64, device=dev)

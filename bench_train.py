@@ -109,9 +109,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         updater.update({"packed": packed})
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0      # this rank's K steps; the job time is the MAX over ranks (below)
-    fence()                                 # closing barrier: not part of any rank's steps
+    fence()
+    elapsed = time.perf_counter() - t0
     loss = model.reporter.observation["loss"]
     stats = torch.tensor([elapsed, frames], dtype=torch.float64, device=dev)
     if dist is not None:
