@@ -470,14 +470,14 @@ extern "C" long long fs2_colreduce_workspace(int M, int C, int R) {
     return (long long)nblk(M > 0 ? M : 1, CR_ROWS) * R * C * (long long)sizeof(float);
 }
 
-extern "C" int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
-                             const int* pos, float* out, float* workspace, int M, int C, float scale, int accumulate,
-                             hipStream_t stream) {
-    FS2_CHECK_ARG(G && out && workspace, "fs2_colreduce: null pointer");
-    FS2_CHECK_ARG(g_dtype >= 0 && g_dtype <= 2, "fs2_colreduce: g_dtype=%d (0 fp32, 1 bf16)", g_dtype);
+static int colreduce_launch(const char* name, const void* G, int g_dtype, int ldg, const float* S, int lds, int R,
+                            const float* pe, const int* pos, float* out, float* workspace, int M, int C, float scale,
+                            int accumulate, hipStream_t stream) {
+    FS2_CHECK_ARG(G && out && workspace, "%s: null pointer", name);
+    FS2_CHECK_ARG(g_dtype >= 0 && g_dtype <= 2, "%s: g_dtype=%d (0 fp32, 1 bf16)", name, g_dtype);
     FS2_CHECK_ARG(R >= 1 && R <= CR_MAXR && (S || R == 1) && C > 0 && ldg >= C && (!S || lds >= R),
-                  "fs2_colreduce: R=%d (1..%d), C=%d, ldg=%d", R, CR_MAXR, C, ldg);
-    FS2_CHECK_ARG(!pe || (pos && R == 1), "fs2_colreduce: pe mode needs pos and R == 1");
+                  "%s: R=%d (1..%d), C=%d, ldg=%d", name, R, CR_MAXR, C, ldg);
+    FS2_CHECK_ARG(!pe || (pos && R == 1), "%s: pe mode needs pos and R == 1", name);
     const int blocks = nblk(M > 0 ? M : 1, CR_ROWS);
     if (M <= 0) {
         (void)hipMemsetAsync(workspace, 0, (size_t)R * C * sizeof(float), stream);
@@ -490,8 +490,63 @@ extern "C" int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S
     }
     hipLaunchKernelGGL(colreduce_finish_kernel, dim3(nblk((long long)R * C, 64)), dim3(1024), 0, stream, workspace, out,
                        blocks, R * C, (long long)R * C, scale, accumulate);
-    FS2_CHECK_LAUNCH("fs2_colreduce");
+    FS2_CHECK_LAUNCH(name);
     return FS2_OK;
+}
+
+extern "C" int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
+                             const int* pos, float* out, float* workspace, int M, int C, float scale, int accumulate,
+                             hipStream_t stream) {
+    return colreduce_launch("fs2_colreduce", G, g_dtype, ldg, S, lds, R, pe, pos, out, workspace, M, C, scale, accumulate,
+                            stream);
+}
+
+// ---- the entry point that allocates nothing (include/fs2_hip.h: fs2_colreduce_static) ----------------------------
+// The stage-1 partials live in a file-scope device array instead of a caller workspace.  `scratch` is only the
+// host-side stand-in of that array: its per-device address comes from hipGetSymbolAddress, once per device, and
+// that pointer (never the name) is what the kernels and the memset receive.
+#define FS2_STATIC_SCRATCH_BYTES (8ll << 20)
+static __device__ __align__(256) unsigned char scratch[FS2_STATIC_SCRATCH_BYTES];
+static float* g_scratch_ptr[64];          // per device ordinal; written once, read with atomics
+
+static int static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        fs2_set_error("fs2_colreduce_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return FS2_ERR_HIP;
+    }
+    float* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        void* sym = nullptr;
+        e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sym) {
+            fs2_set_error("fs2_colreduce_static: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+            return FS2_ERR_HIP;
+        }
+        p = (float*)sym;
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+    }
+    *out = p;
+    return FS2_OK;
+}
+
+extern "C" long long fs2_colreduce_static_max_bytes(void) { return FS2_STATIC_SCRATCH_BYTES; }
+
+extern "C" int fs2_colreduce_static(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
+                                    const int* pos, float* out, int M, int C, float scale, int accumulate,
+                                    hipStream_t stream) {
+    FS2_CHECK_ARG(R >= 1 && R <= CR_MAXR && C > 0, "fs2_colreduce_static: R=%d (1..%d), C=%d", R, CR_MAXR, C);
+    const long long need = fs2_colreduce_workspace(M, C, R);
+    FS2_CHECK_ARG(need <= FS2_STATIC_SCRATCH_BYTES,
+                  "fs2_colreduce_static: M=%d C=%d R=%d needs %lld bytes of partials, the static scratch holds %lld; "
+                  "use fs2_colreduce with a caller workspace",
+                  M, C, R, need, (long long)FS2_STATIC_SCRATCH_BYTES);
+    float* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != FS2_OK) return rc;
+    return colreduce_launch("fs2_colreduce_static", G, g_dtype, ldg, S, lds, R, pe, pos, out, ws, M, C, scale, accumulate,
+                            stream);
 }
 
 extern "C" int fs2_rowdot_bwd(const float* dy, const float* W, float* dx, int M, int C, int nout, hipStream_t stream) {

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "fs2_conv_wgrad": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "fs2_layernorm_bwd": [_P, _P, _P, _I, _L, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _U, _U, _F, _U, _F, _P],
     "fs2_colreduce": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "fs2_colreduce_static": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_rowdot_bwd": [_P, _P, _P, _I, _I, _I, _P],
     "fs2_lr_scatter": [_P, _P, _P, _P, _P, _I, _P, _F, _P, _I, _I, _P],
     "fs2_embed_bwd": [_P, _P, _F, _P, _I, _I, _I, _I, _P],
@@ -68,6 +69,7 @@ _SIZE_QUERIES = {
     "fs2_conv_wgrad_workspace": [_I, _I, _I, _I],
     "fs2_layernorm_bwd_workspace": [_I, _I],
     "fs2_colreduce_workspace": [_I, _I, _I],
+    "fs2_colreduce_static_max_bytes": [],
 }
 # plain int queries (no launch, cannot fail)
 _INT_QUERIES = {

@@ -237,6 +237,17 @@ long long fs2_colreduce_workspace(int M, int C, int R);
 int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe, const int* pos,
                   float* out, float* workspace, int M, int C, float scale, int accumulate, hipStream_t stream);
 
+/* fs2_colreduce without a caller workspace and without any allocation.  NO counterpart in the reference: it exists
+ * for callers that cannot allocate device memory around a call (code under HIP graph capture, tight serving /
+ * training loops, harnesses that forbid hipMalloc).  The stage-1 partials go to a static device array of
+ * fs2_colreduce_static_max_bytes() = 8 MiB that every GPU the library runs on holds until the process ends; a
+ * shape whose fs2_colreduce_workspace(M, C, R) exceeds that is rejected with FS2_ERR_ARG.  Same kernels, same
+ * summation order, bit-identical results to fs2_colreduce.  All calls on one GPU share that array: calls that
+ * overlap on one GPU (different streams or threads) race — serialise them. */
+long long fs2_colreduce_static_max_bytes(void);
+int fs2_colreduce_static(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
+                         const int* pos, float* out, int M, int C, float scale, int accumulate, hipStream_t stream);
+
 /* dx[m, :] = sum_j dy[m, j] * W[j, :] — input gradient of fs2_rowdot. */
 int fs2_rowdot_bwd(const float* dy, const float* W, float* dx, int M, int C, int nout, hipStream_t stream);
 
