@@ -92,6 +92,97 @@ def test_bf16_with_fp32_encoder_keeps_durations_exact():
         assert np.abs(out["mel"][i, :T].cpu().numpy() - z["mel_%d" % i]).max() <= BF16_MEL_TOL
 
 
+@pytest.mark.parametrize("name", helpers.LONG_CASES)
+def test_long_utterance_config4(name):
+    """BASELINE config 4: 512 phones -> 4165 frames at BASELINE dims against the reference's own output (sampled mel
+    rows + row / column sums of every frame), alone and as one row of a 4-utterance batch; fp32 to the north_star
+    bars, bf16 (teacher-forced durations) to the stated bf16 tolerance."""
+    z, meta = helpers.load_golden(name)
+    ids = torch.from_numpy(z["ids_0"])
+    T = int(z["frames_0"])
+    rows = helpers.long_mel_rows(T)
+    idx, _ = fs2_oracle.length_regulate_index(z["dur_pred_0"])
+    model = build_model(meta)
+    # a short utterance first: the cached positional table (1024 rows) has to re-grow for 4165 frames
+    assert model.inference(ids[:9].cuda(), None).shape[1] == meta["cfg"]["odim"]
+    others = [ids[:300], ids[100:], torch.flip(ids, [0])]
+    for xs in ([ids], [ids] + others):
+        out = model.infer_batch(xs)
+        pk = out["packed"]
+        assert pk["olens"][0] == T
+        assert np.array_equal(pk["durations_pred"].cpu().numpy()[:512], z["dur_pred_0"])
+        assert np.array_equal(pk["durations"].cpu().numpy()[:512], z["dur_after_lr_0"])
+        assert np.array_equal(pk["lr_index"].cpu().numpy()[:T], idx)
+        mel = out["mel"][0, :T].cpu().numpy()
+        assert np.abs(mel[rows] - z["mel_rows_0"]).max() <= FP32_MEL_TOL
+        assert np.abs(mel.astype(np.float64).sum(1) - z["mel_rowsum_0"]).max() <= 80 * FP32_MEL_TOL
+        assert np.abs(mel.astype(np.float64).sum(0) - z["mel_colsum_0"]).max() <= T * FP32_MEL_TOL
+        assert np.abs(pk["enc_out"].cpu().numpy()[:512][::8] - z["enc_out_0"]).max() <= 1e-3
+        assert np.abs(pk["pitch"].cpu().numpy()[:T] - z["pitch_0"]).max() <= 1e-3
+        assert np.abs(pk["energy"].cpu().numpy()[:T] - z["energy_0"]).max() <= 1e-3
+    # bf16, durations teacher-forced from the reference
+    eng = build_model(meta, "bf16").engine()
+    ds = torch.from_numpy(z["dur_after_lr_0"].astype(np.int32)).cuda()
+    out = eng.forward(ids.cuda(), [512], ds=ds)
+    mel = out["mel"].cpu().numpy()
+    assert mel.shape[0] == T
+    assert np.abs(mel[rows] - z["mel_rows_0"]).max() <= BF16_MEL_TOL
+    assert np.sqrt(np.mean((mel[rows] - z["mel_rows_0"]) ** 2)) <= BF16_MEL_RMS_TOL
+    assert np.array_equal(out["lr_index"].cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("precision,tol,flips", [("fp32", FP32_MEL_TOL, 0.001), ("bf16", BF16_MEL_TOL, 0.02)])
+def test_config3_eight_shards_equal_one_rank(precision, tol, flips):
+    """BASELINE config 3: 256 utterances decoded by 8 ranks (decode(..., rank=r, world_size=8), here one after the
+    other on this GPU) against the same 256 decoded by a single rank: the shards partition the set, and every
+    utterance has the same durations and mel whichever rank and batch it went through (other batch compositions =
+    other tile / split-K shapes = other fp32 summation orders: at most `flips` of the phones may differ by one frame,
+    utterances with equal durations agree to the precision's tolerance).  In fp32, sampled utterances are also held
+    against the CPU oracle (durations exact, mel <= 1e-3)."""
+    from argparse import Namespace
+    from fastspeech2_amd import synth
+    from fastspeech2_amd.run.fastspeech_decode import decode
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = synth.bench_state_dict()
+    model = FeedForwardTransformer(80, 80, use_scaled_pos_enc=True, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval().cuda().set_precision(precision)
+    utts = {"utt%03d" % i: x for i, x in enumerate(synth.synth_utterances(256, 0, sort=False))}
+    cfg = Namespace(DATASET=Namespace(VAL=Namespace(UTTERANCES=utts)), DECODE=Namespace(BATCH_SIZE=32))
+    one = decode(cfg, model, 0, None)
+    assert sorted(one) == sorted(utts)
+    shards = [decode(cfg, model, 0, None, rank=r, world_size=8) for r in range(8)]
+    assert all(len(s) == 32 for s in shards)
+    union = {}
+    for s in shards:
+        assert not (set(s) & set(union))
+        union.update(s)
+    assert sorted(union) == sorted(utts)
+    frames = [sum(v["mel_length"] for v in s.values()) for s in shards]
+    assert max(frames) <= 1.05 * min(frames)                 # length-sorted round-robin deal balances the ranks
+    phones = differing = compared = 0
+    for k, a in one.items():
+        b = union[k]
+        delta = a["durations"] - b["durations"]
+        phones += delta.size
+        differing += int((delta != 0).sum())
+        assert np.abs(delta).max() <= 1
+        if (delta != 0).any():
+            continue
+        assert a["mel_length"] == b["mel_length"]
+        assert np.abs(a["mel_postnet"] - b["mel_postnet"]).max() <= tol, k
+        compared += 1
+    assert differing <= flips * phones, (differing, phones)
+    assert compared >= (240 if precision == "fp32" else 100), compared
+    if precision == "fp32":
+        cfg_o = fs2_oracle.full_cfg(80, 80, use_scaled_pos_enc=True, **kw)
+        sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
+        for k in ("utt000", "utt101", "utt255"):
+            o = fs2_oracle.infer_one(sd_t, cfg_o, torch.from_numpy(utts[k]))
+            assert np.array_equal(union[k]["durations"], o["durations"].numpy())
+            assert np.abs(union[k]["mel_postnet"] - o["mel"].numpy()).max() <= FP32_MEL_TOL
+
+
 @pytest.mark.parametrize("name", helpers.TRAIN_CASES)
 def test_training_forward_loss_matches_reference(name):
     z, meta = helpers.load_golden(name)

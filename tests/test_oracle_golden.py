@@ -34,6 +34,40 @@ def test_oracle_matches_reference_inference(name):
             assert np.abs(out["mel_before"].numpy() - z["mel_before_%d" % i]).max() <= tol
 
 
+@pytest.mark.parametrize("name", helpers.LONG_CASES)
+def test_oracle_matches_reference_long_utterance(name):
+    """BASELINE config 4 (512 phones -> 4165 frames): sampled mel rows, row / column sums of all frames."""
+    z, meta = helpers.load_golden(name)
+    sd, cfg = helpers.golden_state_dict(meta), helpers.oracle_cfg(meta)
+    out = fs2_oracle.infer_one(sd, cfg, torch.from_numpy(z["ids_0"]))
+    assert np.array_equal(out["durations_pred"].numpy(), z["dur_pred_0"])
+    assert np.array_equal(out["durations_reported"].numpy(), z["dur_after_lr_0"])
+    T = int(z["frames_0"])
+    mel = out["mel"].numpy()
+    assert mel.shape[0] == T
+    assert np.abs(out["enc_out"].numpy()[::8] - z["enc_out_0"]).max() <= MEL_TOL_BIG
+    assert np.abs(out["pitch"].numpy() - z["pitch_0"]).max() <= MEL_TOL_BIG
+    assert np.abs(out["energy"].numpy() - z["energy_0"]).max() <= MEL_TOL_BIG
+    assert np.abs(mel[helpers.long_mel_rows(T)] - z["mel_rows_0"]).max() <= MEL_TOL_BIG
+    assert np.abs(mel.astype(np.float64).sum(1) - z["mel_rowsum_0"]).max() <= 80 * MEL_TOL_BIG
+    assert np.abs(mel.astype(np.float64).sum(0) - z["mel_colsum_0"]).max() <= T * MEL_TOL_BIG
+
+
+def test_oracle_matches_reference_baseline_size_training_step():
+    """BASELINE config 5 shapes (B=32, 120 phones -> 781 frames each, 4+4 blocks): loss terms and gradient samples."""
+    z, meta = helpers.load_golden(helpers.BIG_TRAIN_CASES[0])
+    sd, cfg = helpers.golden_state_dict(meta), helpers.oracle_cfg(meta)
+    batch = helpers.train_inputs(meta["cfg"], meta["seed"], **meta["inputs"])
+    assert np.array_equal(batch[4], z["ds"])
+    terms, grads = fs2_oracle.train_grads(sd, cfg, *[torch.from_numpy(a) for a in batch])
+    for k in ("l1_loss", "duration_loss", "pitch_loss", "energy_loss", "loss"):
+        assert abs(terms[k] - meta["losses"][k]) <= 2e-5 * max(1.0, abs(meta["losses"][k])), k
+    for k in meta["grad_names"]:
+        want, got, wstat, gstat = helpers.golden_grad_sample(z, meta, k, grads[k])
+        assert np.abs(want - got).max() <= 1e-4 * max(np.abs(want).max(), 1e-2), k
+        assert abs(wstat[1] - gstat[1]) <= 1e-4 * max(wstat[1], 1e-2), k
+
+
 @pytest.mark.parametrize("name", helpers.TRAIN_CASES)
 def test_oracle_matches_reference_loss(name):
     z, meta = helpers.load_golden(name)
