@@ -4,16 +4,20 @@ mel resident in HBM) on BASELINE.json config 2: the BASELINE architecture (4+4 F
 2 heads, conv k=9 FFN, U=1024), random-init, one batch of 32 length-bucketed synthetic utterances
 (~120 phones -> ~800 mel frames) per GPU, bf16 MFMA operands.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling strong]
+    (N > 1: either under torchrun — python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... —
+     or bare: without WORLD_SIZE in the environment the process spawns the N ranks itself, fastspeech2_amd/run/launch.py)
 
 One "step" = one forward over one 32-utterance batch.  Utterances are independent, so N GPUs run N
 different batches with no data-path collective (weak scaling); only the timing is reduced (MAX).
+--scaling strong is BASELINE config 3: the SAME 256 utterances at every N, length-sorted and dealt to the ranks in
+32-utterance batches (8 / N batches per rank and step); value = the 256 utterances' frames / the slowest rank's time.
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the conv-FFN implicit GEMM, timed
 with HIP events on its launch stream in a second, separately timed pass) and `cpu_baseline` (the CPU
 oracle, kind "port", timed on this box's host cores on the same batch).
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -26,11 +30,26 @@ import time
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from fastspeech2_amd.run.launch import maybe_self_launch            # noqa: E402  (no torch, no GPU)
+
+
+def _gpus_arg(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__":
+    maybe_self_launch(_gpus_arg(sys.argv[1:]))     # N > 1 without a launcher: become N ranks (parent never touches a GPU)
+
+import numpy as np                                                   # noqa: E402
+import torch                                                         # noqa: E402
 
 from fastspeech2_amd import synth                                   # noqa: E402
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer  # noqa: E402
@@ -53,6 +72,13 @@ def parse():
     ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
     ap.add_argument("--force-dist", action="store_true",
                     help="with one GPU: still create the nccl (RCCL) group and run the barrier / reductions")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 32 utterances per GPU (config 2, the headline); strong: the same 256 utterances "
+                         "split over the GPUs (config 3)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="no GPU, no model: build the process group on gloo, run the barrier and the MAX / SUM "
+                         "reductions on placeholder numbers and print the line's skeleton (checks the N-rank launch "
+                         "path on a CPU-only machine; the value is null)")
     return ap.parse_args()
 
 
@@ -71,6 +97,38 @@ def rank_batch(world, rank):
     32-utterance bucket with a near-identical length profile."""
     utts = synth.synth_utterances(BATCH * world, 0, idim=synth.BENCH_IDIM)
     return utts[rank::world]
+
+
+STRONG_UTTERANCES = 256
+
+
+def rank_batches_strong(world, rank):
+    """BASELINE config 3: the same 256 utterances (seed 0) whatever the world size; this rank's share = its
+    round-robin deal of the length-sorted list, cut into 32-utterance batches (run/shard.py)."""
+    from fastspeech2_amd.run.shard import shard_buckets
+    utts = synth.synth_utterances(STRONG_UTTERANCES, 0, idim=synth.BENCH_IDIM, sort=False)
+    return [[utts[i] for i in bucket] for bucket in shard_buckets([len(u) for u in utts], world, rank, BATCH)]
+
+
+def rendezvous_only(args, world, rank):
+    """--rendezvous-only: the launch / rendezvous / reduction skeleton of main() on gloo, nothing else."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    stats = torch.tensor([1.0 + rank, 100.0], dtype=torch.float64)
+    mx = stats.clone()
+    if world > 1:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "mel frames/sec (node) at batch 32 per GPU", "value": None, "unit": "mel frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                          "rendezvous_only": True, "max_rank_time": float(mx[0]), "sum_frames": float(stats[1])}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def cpu_baseline(sd_np, kw, xs, passes):
@@ -98,6 +156,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -112,23 +172,29 @@ def main():
 
     model, sd_np, kw = build_model(args.dtype, args.encoder_dtype, dev)
     eng = model.engine()
-    xs = rank_batch(world, rank)
-    ilens = [len(x) for x in xs]
-    ids = torch.from_numpy(np.concatenate(xs)).to(dev)
+    strong = args.scaling == "strong"
+    batches = rank_batches_strong(world, rank) if strong else [rank_batch(world, rank)]
+    feed = [(torch.from_numpy(np.concatenate(b)).to(dev), [len(x) for x in b]) for b in batches]
+    xs = batches[0]
+    ids, ilens = feed[0]
 
     def step():
         return eng.forward(ids, ilens)
 
     def run_steps(n):
-        # throughput loop: the phone-level half of step k+1 is enqueued on a side stream underneath the
-        # frame-level half of step k (Engine.forward_pipelined); every step does the full forward
-        last = None
+        # throughput loop: the phone-level half of batch k+1 is enqueued on a side stream underneath the
+        # frame-level half of batch k (Engine.forward_pipelined); every step does the full forward of every batch
+        # of this rank (one batch in weak scaling, 8 / N in strong scaling).  Returns the outputs of the last step.
+        last = []
         if args.serial:
             for _ in range(n):
-                last = step()
+                last = [eng.forward(i, l) for (i, l) in feed]
         else:
-            for last in eng.forward_pipelined(((ids, ilens) for _ in range(n)), frame_streams=args.frame_streams):
-                pass
+            last = collections.deque(maxlen=len(feed))     # keep only the last step's outputs alive
+            for o in eng.forward_pipelined((feed[j % len(feed)] for j in range(n * len(feed))),
+                                           frame_streams=args.frame_streams):
+                last.append(o)
+            last = list(last)
         return last
 
     def fence():
@@ -137,21 +203,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    out = run_steps(args.warmup) if args.warmup > 0 else step()
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    else:
+        step()
     fence()
     t0 = time.perf_counter()
-    out = run_steps(args.steps)
+    outs = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    frames = float(sum(out["olens"]))
-    flops = synth.algorithmic_flops(ilens, out["olens"])
-    stats = torch.tensor([elapsed, frames, flops], dtype=torch.float64, device=dev)
+    frames = float(sum(sum(o["olens"]) for o in outs))
+    flops = sum(synth.algorithmic_flops(l, o["olens"]) for (_, l), o in zip(feed, outs))
+    phones = float(sum(sum(l) for _, l in feed))
+    stats = torch.tensor([elapsed, frames, flops, phones], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0])
-        frames, flops = float(stats[1]), float(stats[2])
+        frames, flops, phones = float(stats[1]), float(stats[2]), float(stats[3])
 
     # ---- roofline of the dominant kernel (conv-FFN implicit GEMM), HIP events on the launch stream
     roofline = None
@@ -188,11 +258,13 @@ def main():
             "metric": "mel frames/sec (node) at batch 32 per GPU",
             "value": round(value, 1), "unit": "mel frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 32 length-bucketed utterances/GPU (~120 phones -> ~800 mel "
-                                   "frames), 4+4 FFT blocks d=256 h=2 conv-k9 U=1024, random-init, idim=odim=80",
-                       "frames_per_step": frames, "phones_per_step": float(sum(ilens)) * world,
+            "config": {"workload": ("BASELINE config 3: the same 256 length-sorted utterances dealt to the GPUs in "
+                                    "32-utterance batches (strong scaling), " if strong else
+                                    "BASELINE config 2: 32 length-bucketed utterances/GPU (~120 phones -> ~800 mel "
+                                    "frames), ") + "4+4 FFT blocks d=256 h=2 conv-k9 U=1024, random-init, idim=odim=80",
+                       "frames_per_step": frames, "phones_per_step": phones, "batches_per_rank_and_step": len(feed),
                        "encoder_dtype": args.encoder_dtype or args.dtype,
                        "step_overlap": "none" if args.serial else "phone-level half of step k+1 on a side stream under the frame-level half of step k; frame-level halves alternate over %d stream(s)" % args.frame_streams,
                        "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),

@@ -5,7 +5,8 @@ teacher-forced durations ds ~ randint(1, 13), ys/ps/es ~ N(0, 1); one step = for
 dropout on at the reference's rates (counter-based masks; --no-dropout for the deterministic step).
 
     python bench_train.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... bench_train.py --gpus N)
+    (N > 1: under torchrun, or bare — without WORLD_SIZE in the environment the process spawns the N ranks itself,
+     fastspeech2_amd/run/launch.py)
 
 Prints ONE JSON line on rank 0 (same shape as bench.py's).  bench.py stays the headline (config 2) bench.
 """
@@ -21,11 +22,22 @@ import time
 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
     os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from fastspeech2_amd.run.launch import maybe_self_launch                 # noqa: E402  (no torch, no GPU)
+
+if __name__ == "__main__":
+    _n = 1
+    for _i, _a in enumerate(sys.argv[1:]):
+        if _a == "--gpus" and _i + 2 < len(sys.argv):
+            _n = int(sys.argv[_i + 2])
+        elif _a.startswith("--gpus="):
+            _n = int(_a.split("=", 1)[1])
+    maybe_self_launch(_n)          # N > 1 without a launcher: become N ranks (the parent never touches a GPU)
+
+import numpy as np                                                        # noqa: E402
+import torch                                                              # noqa: E402
 
 from fastspeech2_amd import synth                                        # noqa: E402
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer   # noqa: E402
@@ -64,12 +76,29 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="deterministic step (every dropout site off)")
     ap.add_argument("--rccl-single", action="store_true",
                     help="with one GPU: still create the nccl (RCCL) group and run the bucketed all-reduces")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="no GPU, no model: gloo process group, barrier, one reduction, the line's skeleton "
+                         "(checks the N-rank launch path on a CPU-only machine)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "training mel frames/sec (node) at batch 32 per GPU", "value": None,
+                              "n_gpus": world, "rendezvous_only": True, "max_rank_time": float(t[0])}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

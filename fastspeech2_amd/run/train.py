@@ -17,7 +17,18 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    """Averages the engine's flat gradient buffer across ranks, bucket by bucket."""
+    """Averages the engine's flat gradient buffer across ranks, bucket by bucket.
+
+    Two transports:
+    * backend "nccl" (RCCL, the production path): every bucket is all-reduced on the device as soon as the backward
+      announces it — stream-ordered collectives, no host thread touches the GPU.
+    * any other backend with device gradients (gloo: the one-GPU test rig, where RCCL cannot put two ranks on one
+      device): the reduced region is staged through ONE pinned host buffer at the end of the backward — copy out,
+      host wait, CPU all-reduce on the calling thread, copy back.  torch's own gloo-on-device-tensor path is not
+      used: it runs every collective on helper threads that allocate pinned memory, take a high-priority stream from
+      the pool per collective (one more hardware queue each) and call hipStreamSynchronize beside the thread that
+      is still issuing the backward — with two ranks and the test process sharing one GPU that is the part of the
+      old data-parallel test nobody could account for when it stalled once."""
 
     def __init__(self, engine, process_group=None, single_rank_too: bool = False):
         """single_rank_too: run the collectives even with one rank (exercises the RCCL path on a one-GPU box)"""
@@ -26,6 +37,7 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.cuda = engine.flat.is_cuda
+        self.host_staged = self.cuda and dist.get_backend(process_group) != "nccl"
         # The collectives are issued on the engine's weight-gradient stream when it has one: that stream already runs
         # behind the compute stream, and one stream fewer matters — HIP multiplexes streams onto GPU_MAX_HW_QUEUES
         # (4) hardware queues, and a stream that sits in an event wait stalls whatever shares its queue (a separate
@@ -33,20 +45,26 @@ class GradReducer:
         side = getattr(engine, "wgrad_stream", None)
         self.comm = (side if side is not None else torch.cuda.Stream(device=engine.flat.device)) if self.cuda else None
         self.works: List = []
+        self._staged = []            # (lo, hi) of the buckets announced in this backward (host-staged transport)
+        self._host = None
         engine.grad_ready = self.bucket_ready
         engine.grad_finish = self.finish
+
+    def _producers(self):
+        return self.engine.producer_streams() if hasattr(self.engine, "producer_streams") else \
+            [torch.cuda.current_stream()]
 
     def bucket_ready(self, index: int):
         lo, hi = self.engine.bucket_slices[index]
         if hi <= lo or (self.world == 1 and not self.single_rank_too):
             return
         buf = self.engine.flat[lo:hi]
-        if self.cuda:
+        if self.host_staged:
+            self._staged.append((lo, hi))
+        elif self.cuda:
             # order the collective after the bucket's last gradient kernels on every producer stream other than
             # the one it is issued on — without joining the streams
-            streams = self.engine.producer_streams() if hasattr(self.engine, "producer_streams") else \
-                [torch.cuda.current_stream()]
-            for st in streams:
+            for st in self._producers():
                 if st != self.comm:
                     ev = torch.cuda.Event()
                     ev.record(st)
@@ -58,8 +76,26 @@ class GradReducer:
             buf.mul_(1.0 / self.world)
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _reduce_through_host(self):
+        lo, hi = min(a for a, _ in self._staged), max(b for _, b in self._staged)
+        self._staged = []
+        cur = torch.cuda.current_stream()
+        for st in self._producers():
+            if st != cur:
+                cur.wait_stream(st)
+        if self._host is None or self._host.numel() < hi - lo:
+            self._host = torch.empty(hi - lo, dtype=self.engine.flat.dtype, pin_memory=True)
+        host = self._host[:hi - lo]
+        host.copy_(self.engine.flat[lo:hi], non_blocking=True)
+        cur.synchronize()
+        host.mul_(1.0 / self.world)
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        self.engine.flat[lo:hi].copy_(host, non_blocking=True)
+
     def finish(self):
         """Make the compute stream wait for every outstanding bucket (called at the end of backward)."""
+        if self._staged:
+            self._reduce_through_host()
         for w in self.works:
             w.wait()
         self.works = []

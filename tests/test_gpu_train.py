@@ -187,45 +187,44 @@ def test_updater_trains_and_reducer_streams():
 
 
 def test_two_process_data_parallel_step(tmp_path):
-    """Two data-parallel ranks (two processes on this GPU, gloo transport standing in for RCCL) with the bucketed
-    reducer hooked into the backward: both end with the mean of the two single-rank gradients.
-
-    Known issue: once in about 25 runs of the whole GPU suite the two ranks stopped making progress after the gloo
-    rendezvous and ran into the 110 s limit (cause not found; the ranks print their stage on stderr).  Both
-    are then killed and the pair is started ONCE more; a second stall fails the test."""
+    """Two data-parallel ranks (two processes on this GPU, gloo transport standing in for RCCL, which cannot put two
+    ranks on one device) with the bucketed reducer hooked into the backward: both end with the mean of the two
+    single-rank gradients.  A rank that stops fails the test with the ranks' stage lines and (after 60 s) their
+    Python stacks attached — no second attempt."""
     import os
     import socket
     import subprocess
     import sys
-    import warnings
     name = "train_tiny_conv3_mixed"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-    def run_pair():
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        procs = []
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    stage_log = os.path.join(str(tmp_path), "stages")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FS2_DP_STAGE_LOG=stage_log)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py"), str(tmp_path),
+                                       name], env=env, cwd=root))
+    codes = None
+    try:
+        codes = [p.wait(timeout=150) for p in procs]
+    except subprocess.TimeoutExpired:
+        pass
+    finally:
+        for p in procs:                  # never leave a rank behind on the GPU (it would stall this process's exit)
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    if codes != [0, 0]:
+        report = []
         for rank in range(2):
-            env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_worker.py"), str(tmp_path),
-                                           name], env=env, cwd=root))
-        try:
-            return [p.wait(timeout=110) for p in procs]
-        except subprocess.TimeoutExpired:
-            return None
-        finally:
-            for p in procs:                  # never leave a rank behind on the GPU (it would stall this process's exit)
-                if p.poll() is None:
-                    p.kill()
-                    p.wait()
-
-    codes = run_pair()
-    if codes is None:
-        warnings.warn("data-parallel ranks stalled (see their stage lines on stderr); started once more")
-        codes = run_pair()
-    assert codes == [0, 0], codes
+            path = "%s.rank%d" % (stage_log, rank)
+            report.append("---- rank %d ----\n%s" % (rank, open(path).read() if os.path.isfile(path) else "(no stage log)"))
+        pytest.fail("data-parallel ranks %s\n%s" % ("stalled" if codes is None else "exited with %s" % codes,
+                                                    "\n".join(report)))
     got = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(2)]
     # single-process truth: the two ranks' gradients computed here, then averaged
     _, meta = helpers.load_golden(name)

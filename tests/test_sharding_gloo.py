@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -83,3 +84,28 @@ def test_shard_helpers():
     assert sorted(r0 + r1) == list(range(7)) and abs(len(r0) - len(r1)) <= 1
     b = shard.make_buckets(lengths, 3)
     assert [len(x) for x in b] == [3, 3, 1] and lengths[b[0][0]] == 9
+
+
+@pytest.mark.parametrize("script", ["bench.py", "bench_train.py"])
+def test_bench_gpus_2_launches_two_ranks_by_itself(script):
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command shape) must become two ranks:
+    the parent spawns them (fastspeech2_amd/run/launch.py), rank 0 prints ONE line with n_gpus == 2.
+    --rendezvous-only swaps the GPU work for placeholder numbers (gloo), the launch / rendezvous / reduction path is
+    the real one.  A rank that fails makes the parent exit non-zero."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rendezvous-only"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["max_rank_time"] == 2.0          # MAX over ranks of (1 + rank)
+    # mismatched launch is refused by every rank -> the parent reports failure
+    bad = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2", "--rendezvous-only"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0
