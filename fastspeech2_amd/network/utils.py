@@ -18,45 +18,45 @@ def pad_list(xs, pad_value):
 
 
 def make_pad_mask(lengths: Union[torch.LongTensor, List[int]], xs: torch.Tensor = None, length_dim: int = -1):
-    """True at padded positions (network/utils.py:59-82)."""
+    """True at padded positions (network/utils.py:59-82).  Without `xs`: (B, max(lengths)).  With `xs`: a mask of
+    xs's shape whose axis `length_dim` is the time axis (broadcast over every other non-batch axis)."""
     if length_dim == 0:
         raise ValueError(f"length_dim cannot be {length_dim}")
-    if not isinstance(lengths, list):
-        lengths = lengths.tolist()
-    bs = len(lengths)
-    maxlen = int(max(lengths)) if xs is None else xs.shape[length_dim]
-    steps = torch.arange(0, maxlen, dtype=torch.int64).unsqueeze(0).expand(bs, maxlen)
-    mask = steps >= torch.tensor(lengths, dtype=torch.int64).unsqueeze(-1)
-    if xs is not None:
-        assert xs.shape[0] == bs, (xs.shape[0], bs)
-        if length_dim < 0:
-            length_dim = xs.dim() + length_dim
-        ind = tuple(slice(None) if i in (0, length_dim) else None for i in range(xs.dim()))
-        mask = mask[ind].expand_as(xs).to(xs.device)
-    return mask
+    lens = torch.as_tensor(lengths, dtype=torch.int64).reshape(-1).cpu()
+    if xs is None:
+        return torch.arange(int(lens.max())) >= lens[:, None]
+    assert xs.shape[0] == lens.numel(), (xs.shape[0], lens.numel())
+    axis = length_dim % xs.dim()
+    shape = [1] * xs.dim()
+    shape[axis] = xs.shape[axis]
+    time = torch.arange(xs.shape[axis]).view(shape)                     # 1 x .. x T x .. x 1
+    shape[axis], shape[0] = 1, lens.numel()
+    return (time >= lens.view(shape)).expand(xs.shape).to(xs.device)
 
 
 def make_non_pad_mask(lengths, xs: torch.Tensor = None, length_dim: int = -1):
     return ~make_pad_mask(lengths, xs, length_dim)
 
 
+_INITS = {
+    "xavier_uniform": lambda w: nn.init.xavier_uniform_(w),
+    "xavier_normal": lambda w: nn.init.xavier_normal_(w),
+    "kaiming_uniform": lambda w: nn.init.kaiming_uniform_(w, nonlinearity="relu"),
+    "kaiming_normal": lambda w: nn.init.kaiming_normal_(w, nonlinearity="relu"),
+}
+
+
 def initialize(model: nn.Module, init_type: str = "pytorch"):
-    """transformer_init handling (network/utils.py:89-109).  As in the reference, the bias-zeroing
-    loop is inert (`p.dim == 1` compares a bound method) and Embedding/LayerNorm are re-initialised."""
+    """transformer_init handling (network/utils.py:89-109): every parameter with more than one axis is re-drawn by the
+    named rule, then Embedding / LayerNorm modules go back to their own defaults.  (The reference also means to zero
+    the biases but tests `p.dim == 1`, a bound method, so that never happens — kept: biases stay as constructed.)"""
     if init_type == "pytorch":
         return
+    if init_type not in _INITS:
+        raise ValueError(f"unknown initialization: {init_type}")
     for p in model.parameters():
         if p.dim() > 1:
-            if init_type == "xavier_uniform":
-                nn.init.xavier_uniform_(p.data)
-            elif init_type == "xavier_normal":
-                nn.init.xavier_normal_(p.data)
-            elif init_type == "kaiming_uniform":
-                nn.init.kaiming_uniform_(p.data, nonlinearity="relu")
-            elif init_type == "kaiming_normal":
-                nn.init.kaiming_normal_(p.data, nonlinearity="relu")
-            else:
-                raise ValueError(f"unknown initialization: {init_type}")
+            _INITS[init_type](p.data)
     for m in model.modules():
         if isinstance(m, (nn.Embedding, nn.LayerNorm)):
             m.reset_parameters()
