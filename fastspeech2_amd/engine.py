@@ -416,7 +416,8 @@ class Engine:
         frame_streams > 1 additionally alternates the frame phases over that many streams, so the tail of one
         batch's kernels overlaps the head of the next batch's.  Same kernels, same results as `forward`;
         yields one output dict per batch, in order (outputs of batch k are ordered after the current stream
-        only once `out["ready"]` has been waited for when frame_streams > 1)."""
+        only once `out["ready"]` has been waited for when frame_streams > 1; the output tensors are registered with
+        the calling stream, so consumers enqueued there after that wait keep them alive)."""
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream(device=self.dev)
             self._fstreams = []
@@ -444,6 +445,12 @@ class Engine:
                     out = self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))
                     out["ready"] = torch.cuda.Event()
                     out["ready"].record()
+                # the outputs were allocated from the frame / side streams' pools: tell the caching allocator that
+                # the caller's stream uses them too, so a block is not handed to the next frame phase while a
+                # consumer the caller enqueued (after waiting for `ready`) is still pending
+                for v in out.values():
+                    if isinstance(v, torch.Tensor) and v.is_cuda:
+                        v.record_stream(main)
                 yield out
             else:
                 yield self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))

@@ -385,9 +385,14 @@ class FeedForwardTransformer(nn.Module):
         """Loss of one teacher-forced step (network/fastspeech2.py:232-295).  Extra keys produced by
         the reference's converter (`labels`, `spkids`, run/train_decode.py:136-149) are ignored.
         In training mode with grad enabled the returned loss carries a backward (HIP kernels, see
-        `_forward_train`); under `torch.no_grad()` / `eval()` it is the plain value (evaluator path,
-        run/train_decode.py:42-57).  Dropout is never applied."""
-        if self.training and torch.is_grad_enabled() and self.postnet is None:
+        `_forward_train`) and dropout follows the constructor's rates (`dropout_enabled = False` turns it off);
+        under `torch.no_grad()` / `eval()` it is the plain value (evaluator path, run/train_decode.py:42-57)."""
+        if self.training and torch.is_grad_enabled():
+            if self.postnet is not None:
+                raise NotImplementedError(
+                    "training with postnet_layers > 0 is not built (DESIGN.md §7: the repaired PostNet's BatchNorm takes "
+                    "its training statistics over padded frames, which the packed layout does not hold); construct "
+                    "the model with postnet_layers=0, or evaluate under torch.no_grad()")
             return self._forward_train(packed if packed is not None else self.pack_batch(xs, ilens, ys, olens, ds, ps, es))
         if xs is None:
             raise ValueError("`packed=` batches are for the training path (train mode, grad enabled)")

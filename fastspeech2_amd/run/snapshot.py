@@ -10,12 +10,22 @@ import tempfile
 import torch
 
 
-def save_snapshot(path, model, optimizer, updater=None, save_func=torch.save):
+def _train_engine_of(model):
+    return getattr(model, "_train_engine", None)
+
+
+def save_snapshot(path, model, optimizer, updater=None, save_func=torch.save, extra=None):
+    """extra: further plain values for the "trainer" dict (epoch, best validation loss, shuffle RNG state), written in
+    the same single pass."""
     model = model.module if hasattr(model, "module") else model              # tools/snapshot.py:22-31
     if hasattr(updater, "finalize"):
         updater.finalize()            # outstanding device-side NaN flags: a skipped step gives back its schedule tick
-    snap = {"trainer": {"iteration": getattr(updater, "iteration", 0), "forward_count": getattr(updater, "forward_count", 0)},
-            "model": model.state_dict(), "optimizer": optimizer.state_dict()}
+    trainer = {"iteration": getattr(updater, "iteration", 0), "forward_count": getattr(updater, "forward_count", 0)}
+    eng = _train_engine_of(model)
+    if eng is not None:
+        trainer["dropout_step"] = int(eng.step)          # counter behind the dropout masks: a resumed run goes on
+    trainer.update(extra or {})
+    snap = {"trainer": trainer, "model": model.state_dict(), "optimizer": optimizer.state_dict()}
     out_dir = os.path.dirname(os.path.abspath(path))
     os.makedirs(out_dir, exist_ok=True)
     tmpdir = tempfile.mkdtemp(prefix="tmp" + os.path.basename(path), dir=out_dir)
@@ -39,4 +49,7 @@ def load_snapshot(path, model, optimizer=None, updater=None, map_location="cpu")
     if updater is not None and isinstance(trainer, dict):
         updater.iteration = int(trainer.get("iteration", 0))
         updater.forward_count = int(trainer.get("forward_count", 0))
+    if isinstance(trainer, dict) and "dropout_step" in trainer and hasattr(model, "train_engine") \
+            and next(model.parameters()).is_cuda:
+        model.train_engine().step = int(trainer["dropout_step"])
     return trainer

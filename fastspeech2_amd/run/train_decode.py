@@ -174,7 +174,8 @@ def train(args) -> Dict[str, float]:
         raise NotImplementedError(f"unknown optimizer: {args.opt}")
     reducer = GradReducer(model.train_engine()) if world > 1 else None
     updater = Updater(model, args.grad_clip, optimizer, device, args.accum_grad, reducer=reducer)
-    start_epoch = 0
+    start_epoch, trainer_state = 0, {}
+    model.train_engine().base_seed = (0x5EED ^ int(args.seed)) & 0xFFFFFFFF          # dropout masks follow --seed
     if args.resume:
         trainer_state = load_snapshot(args.resume, model, optimizer, updater, map_location=device)
         start_epoch = int(trainer_state.get("epoch", 0))
@@ -186,7 +187,12 @@ def train(args) -> Dict[str, float]:
     valid_batches = mk(valid_c) if valid_c is not None else []
     converter = CustomConverter()
     rng = np.random.Generator(np.random.PCG64(args.seed))
-    best, t0, summary = float("inf"), time.time(), {}
+    if "shuffle_rng" in trainer_state:                     # resume: go on with the shuffle sequence, do not replay it
+        st = rng.bit_generator.state
+        st["state"] = {"state": int(trainer_state["shuffle_rng"][0]), "inc": int(trainer_state["shuffle_rng"][1])}
+        rng.bit_generator.state = st
+    best = float(trainer_state.get("best", float("inf")))  # resume: a worse validation must not replace model.loss.best
+    t0, summary = time.time(), {}
     for epoch in range(start_epoch, args.epochs):
         order = np.arange(len(train_batches))
         shuffle = not use_sortagrad or (args.sortagrad != -1 and epoch >= args.sortagrad)     # :388-390
@@ -210,10 +216,9 @@ def train(args) -> Dict[str, float]:
                     best = val["validation/main/loss"]
                     torch.save(model.state_dict(), os.path.join(args.outdir, "model.loss.best"))
         if rank == 0 and done % args.save_interval_epochs == 0:
-            path = save_snapshot(os.path.join(args.outdir, "snapshot.ep.%d" % done), model, optimizer, updater)
-            snap = torch.load(path, map_location="cpu", weights_only=True)
-            snap["trainer"]["epoch"] = done
-            torch.save(snap, path)
+            pcg = rng.bit_generator.state["state"]
+            save_snapshot(os.path.join(args.outdir, "snapshot.ep.%d" % done), model, optimizer, updater,
+                          extra={"epoch": done, "best": best, "shuffle_rng": [str(pcg["state"]), str(pcg["inc"])]})
     updater.finalize()
     summary["iterations"] = updater.iteration
     summary["skipped_steps"] = updater.skipped_steps

@@ -15,6 +15,7 @@ one flat buffer laid out in the order the backward finishes them, so data-parall
 all-reduce contiguous buckets while the rest of the backward is still running (`grad_ready` hook).
 """
 import math
+import os
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -124,7 +125,10 @@ class TrainEngine:
         for k in ("pitch_embed", "energy_embed"):
             if self.rates.get(k, 0.0) > 0.0:
                 raise NotImplementedError("dropout inside the variance embeddings is not built (reference default 0.0)")
+        # dropout masks = hash(seed of the step, site, row, col); the step seed mixes a user seed (`set_seed`), the
+        # data-parallel rank (ranks must not draw the same masks) and the step counter (saved in snapshots)
         self.base_seed = 0x5EED
+        self.rank_seed = int(os.environ.get("RANK", "0") or 0)
         self.step = 0
         self.seed = 0
         self._pe = None
@@ -638,7 +642,7 @@ class TrainEngine:
         dev, d, P, cfg = self.dev, self.d, self.P, self.cfg
         self.drop_on = bool(getattr(self.model, "dropout_enabled", True))
         self.step += 1
-        self.seed = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77) & 0xFFFFFFFF
+        self.seed = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77 + self.rank_seed * 0xC2B2AE3D) & 0xFFFFFFFF
         ev_phone, ev_frame = self.refresh_weights()
         torch.cuda.current_stream().wait_event(ev_phone)
         B = len(ilens)
