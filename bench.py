@@ -55,6 +55,7 @@ from fastspeech2_amd import synth                                   # noqa: E402
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md chip table (dense)
+PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.3 TB/s measured achievable, same guide)
 HOP_SECONDS = 256.0 / 22050.0                    # assumed hop (reference defines none)
 BATCH = 32
 
@@ -65,10 +66,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--encoder-dtype", default=None, choices=[None, "bf16", "fp32"])
+    ap.add_argument("--encoder-dtype", default="f16x3", choices=["bf16", "fp32", "f16x3"],
+                    help="phone-level half (encoder + duration predictor). f16x3 (default): error-compensated fp16 GEMM "
+                         "operands, durations bit-exact vs the fp32 engine / reference goldens; bf16: ~1 %% of the "
+                         "durations differ by one frame; fp32: exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="no cross-step overlap: one forward after the other")
     ap.add_argument("--frame-streams", type=int, default=3, help="alternate the frame-level halves over this many streams")
+    ap.add_argument("--no-pure", action="store_true", help="skip the extra timed loop with the phone-level half in --dtype")
     ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
     ap.add_argument("--force-dist", action="store_true",
                     help="with one GPU: still create the nccl (RCCL) group and run the barrier / reductions")
@@ -223,8 +228,10 @@ def main():
         elapsed = float(mx[0])
         frames, flops, phones = float(stats[1]), float(stats[2]), float(stats[3])
 
-    # ---- roofline of the dominant kernel (conv-FFN implicit GEMM), HIP events on the launch stream
-    roofline = None
+    # ---- rooflines: HIP events on the launch stream around every tagged launch, one forward at a time (a second pass
+    #      over the same steps, outside the timed region).  `roofline` = the dominant kernel (the bf16 k=9 FFN conv
+    #      implicit GEMM of the frame-level half); `rooflines` = the other kernels the north_star names.
+    roofline, rooflines = None, None
     if rank == 0:
         eng.profile = []
         for _ in range(max(3, min(args.steps, 10))):
@@ -232,21 +239,75 @@ def main():
         torch.cuda.synchronize()
         recs = eng.profile
         eng.profile = None
-        t_ms = sum(e0.elapsed_time(e1) for (_, _, _, _, e0, e1) in recs)
-        fl = sum(2.0 * M * N * K for (_, M, N, K, _, _) in recs)
-        n = len(recs)
-        achieved = fl / (t_ms * 1e-3) / 1e12
+        agg = {}
+        for tag, kind, work, e0, e1 in recs:
+            a = agg.setdefault(tag, [kind, 0.0, 0.0, 0])
+            a[1] += work
+            a[2] += e0.elapsed_time(e1)
+            a[3] += 1
         peak = PEAK_TFLOPS[args.dtype]
+
+        def entry(tags, note, mfma_per_product=1):
+            kind = agg[tags[0]][0]
+            work = sum(agg[t][1] for t in tags)
+            t_ms = sum(agg[t][2] for t in tags)
+            n = sum(agg[t][3] for t in tags)
+            if kind == "flop":
+                ach = work / (t_ms * 1e-3) / 1e12
+                e = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach * mfma_per_product / peak, 4),
+                         flops_per_launch=work / n)
+                if mfma_per_product != 1:
+                    e["mfma_per_product"] = mfma_per_product
+            else:
+                ach = work / (t_ms * 1e-3) / 1e9
+                e = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                         bytes_per_launch=work / n)
+            e.update(kernel=note, launches=n, avg_launch_us=round(t_ms * 1e3 / n, 2))
+            return e
+
+        main_tags = [t for t in ("ffn1:" + args.dtype, "ffn2:" + args.dtype) if t in agg]
+        roofline = entry(main_tags, "fs2::conv_gemm_kernel<%s, ..., KT=9> (the k=9 FFN convs of the frame-level half%s; own "
+                         "kernel symbol; timed one forward at a time, i.e. without the cross-batch overlap of the "
+                         "throughput loop)" % (args.dtype, "" if args.encoder_dtype != args.dtype else " and the phone-level half"))
         traffic = None     # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
         tpath = os.path.join(ROOT, "profiles", "r01_ffn_conv_traffic.json")
         if args.dtype == "bf16" and os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        roofline = dict(bound="mfma", kernel="fs2::conv_gemm_kernel<%s, ..., KT=9> (the k=9 FFN convs, own kernel symbol; "
-                                                "timed one forward at a time, i.e. without the cross-batch overlap of "
-                                                "the throughput loop)" % args.dtype,
-                        achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                        traffic=traffic, launches=n, avg_launch_us=round(t_ms * 1e3 / n, 2),
-                        flops_per_launch=fl / n)
+        roofline["traffic"] = traffic
+        rooflines = {}
+        d = args.dtype
+        others = [
+            ("conv_ffn_f16x3", ["ffn1:f16x3", "ffn2:f16x3"], "fs2::conv_gemm_kernel<float, ..., SPLIT> (phone-level FFN convs "
+             "on error-compensated fp16 operands: 3 MFMAs per product; achieved = algorithmic FLOP/s, frac counts the 3 MFMAs)", 3),
+            ("gemm_k1", ["qkv:" + d, "out_proj:" + d, "feat_out:" + d], "fs2::conv_gemm_kernel<%s, ..., KT=0>: the k=1 GEMMs of the "
+             "frame-level half (QKV, output projection, feat_out)" % d, 1),
+            ("attention", ["attention:" + d], "fs2::attention_kernel<%s> (frame-level self-attention, 4 sum(T^2) d FLOP)" % d, 1),
+            ("add_layernorm", ["add_layernorm"], "fs2::add_layernorm_kernel (frame level: residual + split-K partial sum + "
+             "LayerNorm, fp32 + bf16 outputs)", 1),
+            ("lr_gather", ["lr_gather"], "fs2::lr_gather_kernel (LengthRegulator expansion)", 1),
+            ("variance_add_posenc", ["variance_add_posenc"], "fs2::variance_add_posenc_kernel", 1),
+            ("layernorm_rowdot", ["layernorm_rowdot"], "fs2::layernorm_rowdot_kernel (pitch / energy heads)", 1),
+        ]
+        for key, tags, note, mpp in others:
+            tags = [t for t in tags if t in agg]
+            if tags:
+                rooflines[key] = entry(tags, note, mpp)
+
+    # ---- the pure-bf16 figure beside the exact-duration headline (same loop, phone-level half in bf16 too)
+    pure = None
+    if rank == 0 and world == 1 and args.encoder_dtype != args.dtype and not args.no_pure:
+        model.set_precision(args.dtype, args.dtype)
+        eng = model.engine()
+        run_steps(max(args.warmup, 3))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pouts = run_steps(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        pframes = float(sum(sum(o["olens"]) for o in pouts))
+        pure = dict(value=round(pframes * args.steps / dt, 1), ms_per_step=round(dt / args.steps * 1e3, 4),
+                    note="encoder_dtype=%s: about 1 %% of the integer durations differ by one frame from the fp32 engine / "
+                         "reference, so this mode does not meet the bit-exact bar" % args.dtype)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -265,12 +326,15 @@ def main():
                                     "BASELINE config 2: 32 length-bucketed utterances/GPU (~120 phones -> ~800 mel "
                                     "frames), ") + "4+4 FFT blocks d=256 h=2 conv-k9 U=1024, random-init, idim=odim=80",
                        "frames_per_step": frames, "phones_per_step": phones, "batches_per_rank_and_step": len(feed),
-                       "encoder_dtype": args.encoder_dtype or args.dtype,
+                       "encoder_dtype": args.encoder_dtype,
+                       "durations": ("bit-exact vs the fp32 engine and the reference goldens (tests/test_gpu_model.py)"
+                                     if args.encoder_dtype != "bf16" else "~1 % differ by one frame (bf16 encoder)"),
+                       "pure_%s" % args.dtype: pure,
                        "step_overlap": "none" if args.serial else "phone-level half of step k+1 on a side stream under the frame-level half of step k; frame-level halves alternate over %d stream(s)" % args.frame_streams,
                        "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
                        "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu,
         }
         if cpu:
             line["config"]["gpu_over_cpu"] = round(value / cpu["value"], 1)

@@ -50,7 +50,29 @@ struct ConvGemmArgs {
     int krot;                 // 0: every workgroup walks K from (chunk_lo, tap 0); else the walk starts at a per-M-tile phase
     int ksplit;               // split of the channel-chunk range over gridDim.y partial outputs
     long long split_stride;   // elements between two partial outputs
+    float out_scale;          // SPLIT (f16x3) mode: 1 / (power-of-two scale folded into the packed weights); else 1
 };
+
+// ---- f16x3: error-compensated half-precision operands (dtype FS2_F16X3) ---------------------------------------
+// x = xh + xl and w = wh + wl with all four terms fp16 (11 significant bits each, so a pair carries 22 of fp32's
+// 24); the product is accumulated as  wh.xh + wh.xl + wl.xh  on the f16 matrix pipe (fp32 accumulate): the dropped
+// term wl.xl and the split residuals are below 2^-21 of |w||x|.  X arrives as fp32 and is split in registers (one
+// split per fragment, re-used by the NT or MT products it takes part in); W is split once at pack time: a 32-channel
+// chunk of a W row is 128 bytes = [32 x hi][32 x lo], the same bytes per row and chunk as fp32, so staging, swizzle
+// and the LDS geometry are those of the fp32 path.  3 MFMAs of 16 cycles against 8 of 32 for exact-fp32 MFMA.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_f16(const f32x8& x, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)x[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(x[j] - (float)h);       // exact difference (<= 13 significant bits), then rounded to fp16
+    }
+}
+__device__ __forceinline__ f32x4 mma16_f16(const f16x8& a, const f16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
 // 16-byte slot swizzles (see header comment)
 __device__ __forceinline__ int swz_x(int r) { return (r >> 1) & 7; }
@@ -93,7 +115,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
             const size_t mc = (size_t)(mok ? m : a.M - 1);
             f32x4 v[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] + bv[nt];
+            for (int nt = 0; nt < NT; ++nt) v[nt] = acc[mt][nt] * a.out_scale + bv[nt];
             if (a.relu == 1) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -175,7 +197,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
                 for (int r = 0; r < 4; ++r) {
                     const int n = nb + 4 * nt + r;
                     if (n >= a.N) continue;
-                    float s = acc[mt][nt][r];
+                    float s = acc[mt][nt][r] * a.out_scale;
                     if (bias) s += bias[n];
                     if (a.relu == 1) s = fmaxf(s, 0.f);
                     if (a.relu == 2) s = tanhf(s);
@@ -199,8 +221,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
 // OCC: workgroups per CU the register allocation is tuned for.
 // KT: number of taps at compile time (9: the FFN convs get their own kernel symbol, so profiler summaries list
 // them apart from the k = 1 / 3 / 5 GEMMs, and their tap loop bounds are constants), 0: run-time a.taps.
-template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0>
+template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0, bool SPLIT = false>
 __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_kernel(ConvGemmArgs a) {
+    static_assert(!SPLIT || sizeof(T) == 4, "f16x3 works on fp32 activations");
     const int taps = KT ? KT : a.taps;
     constexpr bool DMA = MODE != 0;
     constexpr int NW = 2 * WM;
@@ -340,11 +363,15 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             frag_t wf[NT], xf[MT];
+            f16x8 wh[SPLIT ? NT : 1], wl[SPLIT ? NT : 1];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int r = wrow_base + 4 * nt;
                 const unsigned char* rowp = ws + r * CG_ROWB;
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (SPLIT) {      // [32 x hi | 32 x lo] fp16: slots 0..3 hold hi, 4..7 lo (8 channels each)
+                    wh[nt] = *(const f16x8*)(rowp + ((g ^ swz_w(r)) << 4));
+                    wl[nt] = *(const f16x8*)(rowp + (((4 + g) ^ swz_w(r)) << 4));
+                } else if constexpr (sizeof(T) == 2) {
                     wf[nt] = *(const frag_t*)(rowp + (((ks * 4 + g) ^ swz_w(r)) << 4));
                 } else {
                     const f32x4 v0 = *(const f32x4*)(rowp + (((2 * g) ^ swz_w(r)) << 4));
@@ -370,10 +397,24 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                     if (shift < lo[mt] || shift > hi[mt]) xf[mt] = frag_zero<T>();
             }
             if (ks == 0) mid();
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    f16x8 xh, xl;
+                    split_f16(xf[mt], xh, xl);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(wf[nt], xf[mt], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) {       // small terms first, then the leading product
+                        acc[mt][nt] = mma16_f16(wl[nt], xh, acc[mt][nt]);
+                        acc[mt][nt] = mma16_f16(wh[nt], xl, acc[mt][nt]);
+                        acc[mt][nt] = mma16_f16(wh[nt], xh, acc[mt][nt]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(wf[nt], xf[mt], acc[mt][nt]);
+            }
         }
     };
 
@@ -454,17 +495,25 @@ static int conv_gemm_plan_grid(ConvGemmArgs& a, int BM, int BN, size_t elem) {
     return grid_x;
 }
 
-template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0>
+template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0, bool SPLIT = false>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
     constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
     static unsigned long long lds_ok = 0;
-    fs2_allow_lds((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>, lds, &lds_ok);
+    fs2_allow_lds((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT, SPLIT>, lds, &lds_ok);
     const int grid_x = conv_gemm_plan_grid(a, BM, BN, sizeof(T));
-    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT>), dim3(grid_x, a.ksplit),
+    hipLaunchKernelGGL((conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT, SPLIT>), dim3(grid_x, a.ksplit),
                        dim3(128 * WM), lds, stream, a);
     FS2_CHECK_LAUNCH("fs2_conv_gemm");
     return FS2_OK;
+}
+
+// f16x3 (FS2_F16X3): fp32 X, pre-split fp16 W; Cin % 32 == 0 (checked by the entry point), so always LDS-DMA.
+// Used by the phone-level half only (a few thousand tokens): 64 x 64 tiles when 128 x 128 would leave CUs idle.
+static int dispatch_conv_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
+    const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
+    if (big_blocks < 200) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
+    return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
 }
 
 template <typename T>
@@ -527,7 +576,7 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 static int conv_gemm_entry(const void* X, const void* W, const float* bias, const float* res, const void* gate,
                            float gate_scale, void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr,
                            int ldg, int ldo, int relu, int out_f32, int dtype, int ksplit, long long split_stride,
-                           fs2::Dropout drop, hipStream_t stream) {
+                           fs2::Dropout drop, hipStream_t stream, float w_scale = 1.0f) {
     using namespace fs2;
     FS2_CHECK_ARG(!gate || (ldg >= N && ((uintptr_t)gate & 15) == 0 && ksplit == 1),
                   "fs2_conv_gemm_gated: gate needs ldg >= N, 16-byte alignment and ksplit == 1");
@@ -536,9 +585,11 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
     FS2_CHECK_ARG(taps >= 1 && taps <= CG_MAX_TAPS && (taps & 1), "fs2_conv_gemm: taps=%d (odd, 1..%d)", taps,
                   CG_MAX_TAPS);
     FS2_CHECK_ARG(taps == 1 || seg, "fs2_conv_gemm: taps>1 needs the per-row segment table");
-    FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_conv_gemm: dtype=%d", dtype);
+    FS2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2, "fs2_conv_gemm: dtype=%d", dtype);
+    FS2_CHECK_ARG(dtype != 2 || (Cin % 32 == 0 && !gate && !drop.thresh && w_scale > 0.f),
+                  "fs2_conv_gemm(f16x3): Cin=%d must be a multiple of 32 (whole [hi | lo] chunks); no gate / dropout", Cin);
     FS2_CHECK_ARG(relu >= 0 && relu <= 2, "fs2_conv_gemm: activation code %d (0 none, 1 relu, 2 tanh)", relu);
-    const int epv = dtype == 0 ? 4 : 8;
+    const int epv = dtype == 1 ? 8 : 4;
     FS2_CHECK_ARG(Cin % epv == 0 && ldx % epv == 0 && ldx >= Cin,
                   "fs2_conv_gemm: Cin=%d / ldx=%d must be multiples of %d (16-byte rows)", Cin, ldx, epv);
     FS2_CHECK_ARG(ldo >= N && (!res || ldr >= N), "fs2_conv_gemm: ldo/ldr smaller than N");
@@ -554,6 +605,8 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
     a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.ldx = ldx; a.ldr = ldr; a.ldo = ldo;
     a.relu = relu; a.out_f32 = out_f32; a.n_tiles = 1;
     a.ksplit = ksplit; a.split_stride = ksplit > 1 ? split_stride : 0;
+    a.out_scale = dtype == 2 ? 1.0f / w_scale : 1.0f;
+    if (dtype == 2) return dispatch_conv_gemm_split(a, stream);
     return dtype == 0 ? dispatch_conv_gemm<float>(a, stream) : dispatch_conv_gemm<bf16_t>(a, stream);
 }
 
@@ -612,6 +665,15 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
                              long long split_stride, hipStream_t stream) {
     return conv_gemm_entry(X, W, bias, res, nullptr, 1.f, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, out_f32, dtype,
                            ksplit, split_stride, fs2_make_dropout(0, 0, 0.f), stream);
+}
+
+// fs2_conv_gemm in the f16x3 mode: X fp32 [M, ldx], W packed by fs2_pack_weight_f16x3 (values multiplied by the
+// power of two w_scale before the split), out fp32.  Same tiling, masking and epilogue as fs2_conv_gemm.
+extern "C" int fs2_conv_gemm_f16x3(const void* X, const void* W, float w_scale, const float* bias, const float* res,
+                                   void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
+                                   int relu, int ksplit, long long split_stride, hipStream_t stream) {
+    return conv_gemm_entry(X, W, bias, res, nullptr, 1.f, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, 1, 2, ksplit,
+                           split_stride, fs2_make_dropout(0, 0, 0.f), stream, w_scale);
 }
 
 // Training forward of a conv / linear followed by dropout: out = dropout(act(conv(X) + bias)) (no residual, no split-K).

@@ -450,11 +450,40 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
     if (idx < n) dst[idx] = from_f32<T>(src[idx]);
 }
 
+// f16x3 weight operand (csrc/conv_gemm.hip): src (N, C, k) fp32 in nn.Conv1d / nn.Linear layout ->
+// dst[t][n][C / 32][2][32] fp16 = per 32-channel chunk 32 x hi then 32 x lo of  w * scale,  hi = fp16(w * scale),
+// lo = fp16(w * scale - hi).  One thread per (n, c).
+__global__ void pack_weight_f16x3_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int N, int C, int k,
+                                         float scale) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * C) return;
+    const int n = (int)(idx / C), c = (int)(idx % C);
+    const float* sp = src + ((size_t)n * C + c) * k;
+    for (int t = 0; t < k; ++t) {
+        const float w = sp[t] * scale;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        _Float16* chunk = dst + (((size_t)t * N + n) * (C / 32) + c / 32) * 64;
+        chunk[c % 32] = hi;
+        chunk[32 + c % 32] = lo;
+    }
+}
+
 }  // namespace fs2
 
 using namespace fs2;
 
 static inline int blocks_for(long long n, int per) { return (int)((n + per - 1) / per); }
+
+extern "C" int fs2_pack_weight_f16x3(const float* src, void* dst, int N, int C, int k, float scale, hipStream_t stream) {
+    FS2_CHECK_ARG(src && dst && N > 0 && C > 0 && C % 32 == 0 && k >= 1, "fs2_pack_weight_f16x3: N=%d C=%d (multiple of 32) k=%d",
+                  N, C, k);
+    FS2_CHECK_ARG(scale > 0.f, "fs2_pack_weight_f16x3: scale must be a positive power of two");
+    hipLaunchKernelGGL(pack_weight_f16x3_kernel, dim3(blocks_for((long long)N * C, 256)), dim3(256), 0, stream, src,
+                       (_Float16*)dst, N, C, k, scale);
+    FS2_CHECK_LAUNCH("fs2_pack_weight_f16x3");
+    return FS2_OK;
+}
 
 extern "C" int fs2_build_seg(const int* cu, int B, int* seg, int* pos, int M, hipStream_t stream) {
     FS2_CHECK_ARG(cu && seg && B > 0 && M >= 0, "fs2_build_seg: bad args");

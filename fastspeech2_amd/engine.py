@@ -32,11 +32,60 @@ def posenc_table(T: int, d: int) -> torch.Tensor:
     return pe
 
 
-class _Stack:
-    """Packed weights of one FFT stack (encoder or decoder)."""
+def pack_gemm_weight(w: torch.Tensor, code: int) -> torch.Tensor:
+    """GEMM operand of fs2_conv_gemm from a parameter in nn.Conv1d (N, C, k) / nn.Linear (N, C) layout (fp32, on the
+    device).  F32 / BF16: [k][N][C] in that type.  F16X3: the split-fp16 operand of fs2_conv_gemm_f16x3
+    ([k][N][C/32][2][32] fp16) with the power-of-two scale it was packed with attached as `.fs2_scale` — `Engine._gemm`
+    recognises such a weight and takes the f16x3 entry point."""
+    w3 = w if w.dim() == 3 else w.unsqueeze(-1)
+    N, C, k = w3.shape
+    if code != hip.F16X3:
+        return w3.permute(2, 0, 1).to(hip.TORCH_DTYPE[code]).contiguous()
+    if C % 32 != 0:
+        raise NotImplementedError("f16x3 GEMM operands need input channels in multiples of 32 (got %d)" % C)
+    amax = float(w3.abs().max())
+    scale = 1.0 if amax == 0.0 else 2.0 ** max(-12, min(12, math.floor(math.log2(8192.0 / amax))))
+    out = torch.empty((k, N, C // 32, 2, 32), dtype=torch.float16, device=w.device)
+    call("fs2_pack_weight_f16x3", ptr(w3.contiguous()), ptr(out), N, C, k, scale, stream())
+    out.fs2_scale = scale
+    return out
 
-    def __init__(self, sd, prefix, n_layers, pre_ln, concat_after, ff_type, dev, code):
-        tdt = hip.TORCH_DTYPE[code]
+
+class _NoTimer:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
+class _Timer:
+    """HIP events around one launch on the current stream -> Engine.profile record (tag, kind, work, e0, e1);
+    kind "flop": algorithmic FLOPs, "byte": algorithmic HBM bytes."""
+
+    def __init__(self, sink, tag, kind, work):
+        self.sink, self.tag, self.kind, self.work = sink, tag, kind, float(work)
+
+    def __enter__(self):
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        self.sink.append((self.tag, self.kind, self.work, self.e0, self.e1))
+        return False
+
+
+class _Stack:
+    """Packed weights of one FFT stack (encoder or decoder).  code: storage type of the activations (F32 / BF16);
+    gemm_code: operand form of the GEMM weights (the same, or F16X3 over fp32 activations)."""
+
+    def __init__(self, sd, prefix, n_layers, pre_ln, concat_after, ff_type, dev, code, gemm_code=None):
+        gc = code if gemm_code is None else gemm_code
         self.pre_ln, self.concat_after, self.code = pre_ln, concat_after, code
         f32 = lambda k: sd[prefix + k].detach().to(dev, torch.float32).contiguous()
         self.layers = []
@@ -44,17 +93,13 @@ class _Stack:
             p = "encoders.%d." % i
             L = {}
             wq, wk, wv = (f32(p + "self_atten.linear_%s.weight" % n) for n in "qkv")
-            L["wqkv"] = torch.cat([wq, wk, wv], 0).to(tdt).contiguous()
+            L["wqkv"] = pack_gemm_weight(torch.cat([wq, wk, wv], 0), gc)
             L["bqkv"] = torch.cat([f32(p + "self_atten.linear_%s.bias" % n) for n in "qkv"], 0).contiguous()
-            L["wo"] = f32(p + "self_atten.linear_out.weight").to(tdt).contiguous()
+            L["wo"] = pack_gemm_weight(f32(p + "self_atten.linear_out.weight"), gc)
             L["bo"] = f32(p + "self_atten.linear_out.bias")
             w1, w2 = f32(p + "feed_forward.w1.weight"), f32(p + "feed_forward.w2.weight")
-            if ff_type == "conv1d":
-                L["taps"] = w1.shape[-1]
-                w1, w2 = w1.permute(2, 0, 1), w2.permute(2, 0, 1)
-            else:
-                L["taps"] = 1
-            L["w1"], L["w2"] = w1.to(tdt).contiguous(), w2.to(tdt).contiguous()
+            L["taps"] = w1.shape[-1] if ff_type == "conv1d" else 1
+            L["w1"], L["w2"] = pack_gemm_weight(w1, gc), pack_gemm_weight(w2, gc)
             L["b1"], L["b2"] = f32(p + "feed_forward.w1.bias"), f32(p + "feed_forward.w2.bias")
             L["units"] = L["b1"].shape[0]
             for n in ("norm1", "norm2"):
@@ -62,8 +107,8 @@ class _Stack:
             if concat_after:
                 wc = f32(p + "concat_linear.weight")
                 d = wc.shape[0]
-                L["wc_x"] = wc[:, :d].to(tdt).contiguous()
-                L["wc_a"] = wc[:, d:].to(tdt).contiguous()
+                L["wc_x"] = pack_gemm_weight(wc[:, :d].contiguous(), gc)
+                L["wc_a"] = pack_gemm_weight(wc[:, d:].contiguous(), gc)
                 L["bc"] = f32(p + "concat_linear.bias")
             self.layers.append(L)
         if pre_ln:
@@ -71,8 +116,8 @@ class _Stack:
 
 
 class _Predictor:
-    def __init__(self, sd, prefix, dev, code):
-        tdt = hip.TORCH_DTYPE[code]
+    def __init__(self, sd, prefix, dev, code, gemm_code=None):
+        gc = code if gemm_code is None else gemm_code
         self.code = code
         self.convs = []
         j = 0
@@ -81,7 +126,7 @@ class _Predictor:
             bkey = "%sconv.%d.0.conv.bias" % (prefix, j)
             b = sd[bkey].detach().to(dev, torch.float32).contiguous() if bkey in sd else None
             self.convs.append(dict(
-                w=w.permute(2, 0, 1).to(tdt).contiguous(), b=b, taps=w.shape[-1], chans=w.shape[0],
+                w=pack_gemm_weight(w, gc), b=b, taps=w.shape[-1], chans=w.shape[0],
                 ln_w=sd["%sconv.%d.2.weight" % (prefix, j)].detach().to(dev, torch.float32).contiguous(),
                 ln_b=sd["%sconv.%d.2.bias" % (prefix, j)].detach().to(dev, torch.float32).contiguous()))
             j += 1
@@ -92,17 +137,21 @@ class _Predictor:
 
 class Engine:
     """dtype: 'fp32' (f32 MFMA everywhere) or 'bf16' (bf16 MFMA operands, fp32 accumulate /
-    statistics / residual).  encoder_dtype lets the phone-level half (encoder + duration
-    predictor, which decides the integer durations) run in fp32 while the frame-level half runs
-    in bf16."""
+    statistics / residual).  encoder_dtype sets the phone-level half (encoder + duration predictor, which decides
+    the integer durations) apart from the frame-level half: 'fp32', or 'f16x3' = fp32 activations, attention and
+    statistics with the GEMMs on error-compensated fp16 operands (fs2_conv_gemm_f16x3: fp32-grade durations at about
+    a fifth of the exact-fp32 MFMA time)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, dtype: str = "fp32",
                  encoder_dtype: Optional[str] = None, device=None):
         self.dev = torch.device(device) if device is not None else hip.require_gpu()
         hip.load()
         self.cfg = cfg
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("dtype must be 'fp32' or 'bf16' (f16x3 is a phone-level option: encoder_dtype)")
         self.dec_code = hip.DTYPE_CODE[dtype]
-        self.enc_code = hip.DTYPE_CODE[encoder_dtype or dtype]
+        enc_gemm = hip.DTYPE_CODE[encoder_dtype or dtype]
+        self.enc_code = F32 if enc_gemm == hip.F16X3 else enc_gemm       # storage type of phone-level activations
         self.dtype, self.encoder_dtype = dtype, (encoder_dtype or dtype)
         d = cfg["adim"]
         self.d, self.h = d, cfg["aheads"]
@@ -119,7 +168,7 @@ class Engine:
         self.scaled = cfg["use_scaled_pos_enc"]
         ff = cfg["positionwise_layer_type"]
         self.enc = _Stack(sd, "encoder.", cfg["elayers"], cfg["encoder_normalized_before"],
-                          cfg["encoder_concat_after"], ff, dev, self.enc_code)
+                          cfg["encoder_concat_after"], ff, dev, self.enc_code, enc_gemm)
         self.dec = _Stack(sd, "decoder.", cfg["dlayers"], cfg["decoder_normalized_before"],
                           cfg["decoder_concat_after"], ff, dev, self.dec_code)
         g = lambda k: sd[k].detach().to(dev, torch.float32).contiguous()
@@ -133,7 +182,7 @@ class Engine:
             self.enc_alpha = self.dec_alpha = 1.0
             self.enc_xscale = self.dec_xscale = math.sqrt(d)
         va = "variance_adaptor."
-        self.dur_pred = _Predictor(sd, va + "duration_predictor.", dev, self.enc_code)
+        self.dur_pred = _Predictor(sd, va + "duration_predictor.", dev, self.enc_code, enc_gemm)
         self.pitch_pred = _Predictor(sd, va + "pitch_predictor.", dev, self.dec_code)
         self.energy_pred = _Predictor(sd, va + "energy_predictor.", dev, self.dec_code)
         wp, we = g(va + "pitch_embed.conv.conv.weight"), g(va + "energy_embed.conv.conv.weight")
@@ -142,9 +191,9 @@ class Engine:
         self.wp, self.bp = wp[:, :, 0].contiguous(), g(va + "pitch_embed.conv.conv.bias")
         self.we, self.be = we[:, :, 0].contiguous(), g(va + "energy_embed.conv.conv.bias")
         self.pdim, self.edim = self.wp.shape[1], self.we.shape[1]
-        self.w_out = g("feat_out.weight").to(hip.TORCH_DTYPE[self.dec_code]).contiguous()
+        self.w_out = pack_gemm_weight(g("feat_out.weight"), self.dec_code)
         self.b_out = g("feat_out.bias")
-        self.odim = self.w_out.shape[0]
+        self.odim = self.b_out.shape[0]
         # repaired PostNet: eval-mode BatchNorm folded into the conv (scale on W, shift as bias)
         self.postnet = []
         tdt = hip.TORCH_DTYPE[self.dec_code]
@@ -156,10 +205,10 @@ class Engine:
                 scale = g(p + "weight") / torch.sqrt(g(p + "running_var") + 1e-5)
                 bias = g(p + "bias") - g(p + "running_mean") * scale
                 w = w * scale.view(-1, 1, 1)
-            self.postnet.append(dict(w=w.permute(2, 0, 1).to(tdt).contiguous(), b=bias.contiguous(), taps=w.shape[-1],
+            self.postnet.append(dict(w=pack_gemm_weight(w, self.dec_code), b=bias.contiguous(), taps=w.shape[-1],
                                      cout=w.shape[0], cin=w.shape[1]))
         self._pe = None
-        self.profile = None     # optional list collecting (tag, start_event, end_event)
+        self.profile = None     # optional list collecting (tag, kind, work, start_event, end_event): bench.py rooflines
 
     # ------------------------------------------------------------------ helpers
     def _pe_table(self, T: int) -> torch.Tensor:
@@ -170,6 +219,11 @@ class Engine:
                 self._pe_retired = getattr(self, "_pe_retired", []) + [self._pe]
             self._pe = posenc_table(n, self.d).to(self.dev)
         return self._pe
+
+    def _timed(self, tag, kind, work):
+        if self.profile is None or tag is None:
+            return _NO_TIMER
+        return _Timer(self.profile, tag, kind, work)
 
     def _empty(self, shape, code=None, dtype=None):
         return torch.empty(shape, device=self.dev, dtype=dtype or hip.TORCH_DTYPE[code])
@@ -186,15 +240,17 @@ class Engine:
         if out is None:
             shape = (ksplit, M, N) if ksplit > 1 else (M, N)
             out = self._empty(shape, dtype=torch.float32 if out_f32 else hip.TORCH_DTYPE[code])
-        prof = self.profile is not None and tag is not None
-        if prof:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps,
-             Cin, N, N, int(relu), int(out_f32), code, ksplit, M * N, stream())
-        if prof:
-            e1.record()
-            self.profile.append((tag, M, N, Cin * taps, e0, e1))
+        wscale = getattr(w, "fs2_scale", None)
+        if tag is not None and self.profile is not None:
+            tag = "%s:%s" % (tag, "f16x3" if wscale is not None else ("bf16" if code != F32 else "fp32"))
+        with self._timed(tag, "flop", 2.0 * M * N * Cin * taps):
+            if wscale is not None:          # split-fp16 operand (pack_gemm_weight): fp32 in, fp32 out
+                assert code == F32 and int(relu) in (0, 1)
+                call("fs2_conv_gemm_f16x3", ptr(x), ptr(w), wscale, ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin,
+                     taps, Cin, N, N, int(relu), ksplit, M * N, stream())
+            else:
+                call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps,
+                     Cin, N, N, int(relu), int(out_f32), code, ksplit, M * N, stream())
         return out
 
     def _ln(self, x, w, b, M, C, code, want_f32, want_t, parts=None, sum_out=None):
@@ -203,8 +259,11 @@ class Engine:
         of = self._empty((M, C), dtype=torch.float32) if (want_f32 or (want_t and code == F32)) else None
         ot = self._empty((M, C), code) if (want_t and code != F32) else None
         nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
-        call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
-             M, C, LN_EPS, code, stream())
+        nbytes = M * C * (4.0 * (1 + nparts) + (4.0 if sum_out is not None else 0.0) + (4.0 if of is not None else 0.0) +
+                          (2.0 if ot is not None else 0.0))
+        with self._timed("add_layernorm" if M > 8192 else None, "byte", nbytes):
+            call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
+                 M, C, LN_EPS, code, stream())
         return of, (of if code == F32 else ot)
 
     # ------------------------------------------------------------------ FFT stack
@@ -221,12 +280,15 @@ class Engine:
                 pend = None
             else:
                 a_t = xt
-            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code)
+            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv")
             if attn_dump is not None:
                 attn_dump.append(self._dump_attention(qkv, lens, code))
             ctx = self._empty((M, d), code)
-            call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, code,
-                 stream())
+            prof = self.profile is not None and lens is not None
+            with self._timed("attention:" + ("fp32" if code == F32 else "bf16") if prof else None, "flop",
+                             4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
+                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, code,
+                     stream())
             if st.concat_after:
                 att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
                 pend = self._empty((2, M, d), dtype=torch.float32)
@@ -234,7 +296,7 @@ class Engine:
                 self._gemm(att, L["wc_a"], None, M, d, d, 1, code, out_f32=True, out=pend[1])
             else:
                 pend = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, out_f32=True,
-                                  ksplit=self._ksplit(M, d, d, 1, code))
+                                  ksplit=self._ksplit(M, d, d, 1, code), tag="out_proj")
             # ---- position-wise feed-forward sub-layer (:182-187)
             if st.pre_ln:
                 f_t = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
@@ -273,8 +335,9 @@ class Engine:
             if last and fuse_head:
                 # last LayerNorm + head in one pass over the conv output (the LayerNorm output is not stored)
                 out = self._empty((M, pr.nout), dtype=torch.float32)
-                call("fs2_layernorm_rowdot", ptr(y), ptr(c["ln_w"]), ptr(c["ln_b"]), ptr(pr.lin_w), ptr(pr.lin_b), ptr(out),
-                     M, c["chans"], pr.nout, LN_EPS, stream())
+                with self._timed("layernorm_rowdot", "byte", M * (4.0 * c["chans"] + 4.0 * pr.nout)):
+                    call("fs2_layernorm_rowdot", ptr(y), ptr(c["ln_w"]), ptr(c["ln_b"]), ptr(pr.lin_w), ptr(pr.lin_b),
+                         ptr(out), M, c["chans"], pr.nout, LN_EPS, stream())
                 return out
             y32, cur = self._ln(y, c["ln_w"], c["ln_b"], M, c["chans"], code, last, not last)
             cin = c["chans"]
@@ -368,8 +431,9 @@ class Engine:
         seg_f = self._empty((max(Mf, 1), 2), dtype=torch.int32)
         pos_f = self._empty((max(Mf, 1),), dtype=torch.int32)
         lr_index = self._empty((max(Mf, 1),), dtype=torch.int32)
-        call("fs2_lr_gather", ptr(hs32), ptr(cum), ptr(cu_phone), ptr(cu_frames), B, ptr(hs_lr32), ptr(hs_lrt),
-             ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
+        with self._timed("lr_gather", "byte", Mp * (4.0 * d + 12) + Mf * (4.0 * d + (2.0 * d if dc != F32 else 0.0) + 16)):
+            call("fs2_lr_gather", ptr(hs32), ptr(cum), ptr(cu_phone), ptr(cu_frames), B, ptr(hs_lr32), ptr(hs_lrt),
+                 ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
         if dc == F32:
             hs_lrt = hs_lr32
         pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
@@ -383,14 +447,17 @@ class Engine:
         dec_post = not self.dec.pre_ln
         y32 = self._empty((Mf, d), dtype=torch.float32)
         yt = self._empty((Mf, d), dc) if (dec_post and dc != F32) else None
-        call("fs2_variance_add_posenc", ptr(hs_lr32), ptr(p_in), ptr(e_in), ptr(self.wp), ptr(self.bp), ptr(self.we),
-             ptr(self.be), pscale, escale, ptr(pe), ptr(pos_f), self.dec_xscale, self.dec_alpha, None, ptr(y32),
-             ptr(yt), Mf, d, self.pdim, self.edim, dc, stream())
+        # (the positional table rows are shared by all utterances and stay in L2: not counted as HBM bytes)
+        with self._timed("variance_add_posenc", "byte", Mf * (4.0 * d + 4.0 * (self.pdim + self.edim) + 4 + 4.0 * d +
+                                                              (2.0 * d if yt is not None else 0.0))):
+            call("fs2_variance_add_posenc", ptr(hs_lr32), ptr(p_in), ptr(e_in), ptr(self.wp), ptr(self.bp), ptr(self.we),
+                 ptr(self.be), pscale, escale, ptr(pe), ptr(pos_f), self.dec_xscale, self.dec_alpha, None, ptr(y32),
+                 ptr(yt), Mf, d, self.pdim, self.edim, dc, stream())
         if dc == F32:
             yt = y32
         dec_att = [] if ctx["enc_att"] is not None else None
         z32, zt = self._run_stack(self.dec, y32, yt, seg_f, cu_frames, B, max_ol, Mf, dec_att, olens)
-        before = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True)
+        before = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True, tag="feat_out")
         mel = before
         if self.postnet:      # after = before + postnet(before)   (network/fastspeech2.py:222-225)
             cur = before

@@ -264,7 +264,7 @@ class FeedForwardTransformer(nn.Module):
     def set_precision(self, dtype: str = "fp32", encoder_dtype: Optional[str] = None):
         """'fp32' (parity mode) or 'bf16' (bf16 MFMA operands).  encoder_dtype='fp32' keeps the
         phone-level half — which fixes the integer durations — in fp32 under dtype='bf16'."""
-        assert dtype in ("fp32", "bf16") and encoder_dtype in (None, "fp32", "bf16")
+        assert dtype in ("fp32", "bf16") and encoder_dtype in (None, "fp32", "bf16", "f16x3")
         self._precision = (dtype, encoder_dtype)
         self._engine = None
         return self

@@ -27,6 +27,7 @@ extern "C" {
 
 #define FS2_F32 0
 #define FS2_BF16 1
+#define FS2_F16X3 2   /* fs2_conv_gemm_f16x3 only: fp32 activations, error-compensated fp16 operands (see there) */
 
 #define FS2_OK 0
 #define FS2_ERR_ARG (-1)
@@ -79,6 +80,23 @@ int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long 
 int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* res, void* out, const int* seg,
                   int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int out_f32, int dtype,
                   int ksplit, long long split_stride, hipStream_t stream);
+
+/* fs2_conv_gemm at (nearly) fp32 accuracy on the fp16 matrix pipe — the same nn.Conv1d / nn.Linear layers
+ * (network/encoder.py:16-30, :39-44, :57-60, :89; network/utils.py:22-36) for the phone-level half, whose output
+ * decides the INTEGER durations (network/variance_adaptor.py:128-138): a bf16 GEMM flips ~1 % of them, this mode none
+ * on the fixtures (operand error < 2^-21, the level of fp32 summation-order noise).
+ * X fp32 [M, ldx]; W from fs2_pack_weight_f16x3 (w * w_scale split into fp16 hi + lo); the kernel splits X into
+ * hi + lo in registers and accumulates wl.xh + wh.xl + wh.xh in fp32 (3 MFMAs instead of 8 exact-fp32 ones of
+ * twice the cycles); out fp32 [M, ldo] (or split-K partials) = acc / w_scale + bias, act, + res as fs2_conv_gemm.
+ * |x| and |w * w_scale| must stay inside the fp16 range (65504).  Cin % 32 == 0. */
+int fs2_conv_gemm_f16x3(const void* X, const void* W, float w_scale, const float* bias, const float* res, void* out,
+                        const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int ksplit,
+                        long long split_stride, hipStream_t stream);
+
+/* Weight operand of fs2_conv_gemm_f16x3 from the parameter's own layout src (N, C, k) fp32:
+ * dst[t][n][C / 32][2][32] fp16 (per 32-channel chunk: 32 x hi, 32 x lo of w * scale; 4 bytes per weight).
+ * scale: a power of two that brings max |w| near 2^13 (the fp16 low halves then stay normal numbers). */
+int fs2_pack_weight_f16x3(const float* src, void* dst, int N, int C, int k, float scale, hipStream_t stream);
 
 /* Split-K factor (>= 1) the launch schedules pass as `ksplit` for a GEMM of this shape whose partial outputs
  * an fs2_add_layernorm call sums: 1 unless the tiling would leave most CUs idle.  No launch; no counterpart in

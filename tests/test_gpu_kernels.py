@@ -136,6 +136,59 @@ def test_conv_gemm_frame_level_shapes(cin, n, ksplit, lens):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("taps,cin,n,lens,ksplit", [
+    (9, 256, 1024, [120, 61, 1, 3, 700], 1),        # phone-level first FFN conv (64 x 64 tiles)
+    (9, 1024, 256, [130, 9, 4000], 3),              # second FFN conv, three K ranges, 128 x 128 tiles
+    (1, 256, 768, [77, 300], 1),                    # QKV projection
+    (3, 96, 64, [30, 9], 1),                        # odd small shapes (Cin = 3 chunks of 32, N < tile)
+])
+def test_conv_gemm_f16x3_is_fp32_grade(taps, cin, n, lens, ksplit):
+    """fs2_conv_gemm_f16x3 (error-compensated fp16 operands) against the fp64 convolution of the UNROUNDED fp32
+    operands: the error has to sit at the level of fp32 summation noise (the exact-fp32 MFMA path measures 2e-6 here,
+    a bf16 GEMM 4e-3), not at an operand-rounding level."""
+    g = torch.Generator().manual_seed(taps * 1000 + cin + n)
+    M = sum(lens)
+    x = torch.randn(M, cin, generator=g) * 3.0
+    x[::7] *= 1e-3                                   # small activations: low halves in the fp16 subnormal range
+    w = torch.randn(n, cin, taps, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(n, generator=g) * 0.1
+    res = torch.randn(M, n, generator=g)
+    outs, r0 = [], 0
+    for L in lens:
+        xi = x[r0:r0 + L].t().unsqueeze(0)
+        outs.append(F.conv1d(xi.double(), w.double(), b.double(), padding=(taps - 1) // 2).squeeze(0).t())
+        r0 += L
+    ref = torch.cat(outs, 0)
+    _, _, seg, _ = _seg_tables(lens)
+    from fastspeech2_amd.engine import pack_gemm_weight
+    xd, bd, rd = x.to(DEV).contiguous(), b.to(DEV), res.to(DEV)
+    wd = pack_gemm_weight(w.to(DEV), hip.F16X3)
+    scale = wd.fs2_scale
+    assert scale >= 1.0 and math.log2(scale) == int(math.log2(scale))
+    big = max(1.0, ref.abs().max().item())
+    sg = ptr(seg) if taps > 1 else None
+    if ksplit == 1:
+        for relu, use_res in [(0, False), (1, False), (0, True)]:
+            out = torch.full((M, n), float("nan"), device=DEV)
+            call("fs2_conv_gemm_f16x3", ptr(xd), ptr(wd), scale, ptr(bd), ptr(rd) if use_res else None, ptr(out), sg, M, n,
+                 cin, taps, cin, n, n, relu, 1, 0, stream())
+            exp = ref.clamp_min(0) if relu else ref
+            exp = exp + res.double() if use_res else exp
+            err = (out.cpu().double() - exp).abs().max().item()
+            assert err <= 4e-6 * big, (relu, use_res, err)
+    else:
+        parts = torch.full((ksplit, M, n), float("nan"), device=DEV)
+        call("fs2_conv_gemm_f16x3", ptr(xd), ptr(wd), scale, ptr(bd), None, ptr(parts), sg, M, n, cin, taps, cin, n, n, 0,
+             ksplit, M * n, stream())
+        err = (parts.double().sum(0).cpu() - ref).abs().max().item()
+        assert err <= 4e-6 * big, err
+    # the exact-fp32 path on the same data, for scale
+    w32 = w.permute(2, 0, 1).to(DEV).contiguous()
+    out = torch.empty((M, n), device=DEV)
+    call("fs2_conv_gemm", ptr(xd), ptr(w32), ptr(bd), None, ptr(out), sg, M, n, cin, taps, cin, n, n, 0, 1, hip.F32, 1, 0, stream())
+    assert (out.cpu().double() - ref).abs().max().item() <= 4e-6 * big
+
+
 def test_conv_gemm_ksplit_rule():
     ks = hip.load().fs2_conv_gemm_ksplit
     assert ks(24400, 1024, 256, 9, 1) == 1          # frame-level first FFN conv: 191 x 8 tiles

@@ -183,6 +183,63 @@ def test_config3_eight_shards_equal_one_rank(precision, tol, flips):
             assert np.abs(union[k]["mel_postnet"] - o["mel"].numpy()).max() <= FP32_MEL_TOL
 
 
+@pytest.mark.parametrize("name", ["baseline_4x4", "long_512", "tiny_conv3_mixed_ln", "yaml_dims_2x2", "yaml_shipped_full"])
+def test_bf16_with_f16x3_encoder_keeps_durations_exact(name):
+    """The throughput mode that keeps the integer results exact: frame-level half in bf16, phone-level half (encoder +
+    duration predictor) on error-compensated fp16 GEMM operands (encoder_dtype="f16x3").  Durations, frame counts and
+    the LengthRegulator map equal the REFERENCE's on its golden vectors; mel to the bf16 tolerance."""
+    z, meta = helpers.load_golden(name)
+    model = build_model(meta, "bf16", encoder_dtype="f16x3")
+    xs = [torch.from_numpy(z["ids_%d" % i]) for i in range(meta["n"])]
+    out = model.infer_batch(xs)
+    pk = out["packed"]
+    cu_p = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    cu_f = np.concatenate([[0], np.cumsum(pk["olens"])])
+    for i in range(meta["n"]):
+        assert np.array_equal(pk["durations_pred"].cpu().numpy()[cu_p[i]:cu_p[i + 1]], z["dur_pred_%d" % i])
+        T = int(z["frames_%d" % i])
+        assert pk["olens"][i] == T
+        idx, _ = fs2_oracle.length_regulate_index(z["dur_pred_%d" % i])
+        assert np.array_equal(pk["lr_index"].cpu().numpy()[cu_f[i]:cu_f[i + 1]], idx)
+        enc_ref = z["enc_out_%d" % i]
+        enc = pk["enc_out"].cpu().numpy()[cu_p[i]:cu_p[i + 1]]
+        assert np.abs((enc[::8] if name in helpers.LONG_CASES else enc) - enc_ref).max() <= 1e-4
+        mel = out["mel"][i, :T].cpu().numpy()
+        if name in helpers.LONG_CASES:
+            assert np.abs(mel[helpers.long_mel_rows(T)] - z["mel_rows_%d" % i]).max() <= BF16_MEL_TOL
+        else:
+            assert np.abs(mel - z["mel_%d" % i]).max() <= BF16_MEL_TOL
+
+
+def test_f16x3_encoder_durations_equal_the_fp32_engine_on_the_bench_batch():
+    """BASELINE config 2 batch (32 utterances, 3767 phones): the f16x3 phone-level half against the exact-fp32 engine
+    and the CPU oracle — every duration equal (a pure-bf16 encoder flips ~1 % of them)."""
+    from fastspeech2_amd import synth
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = synth.bench_state_dict()
+    xs = [torch.from_numpy(x) for x in synth.synth_utterances(32, 0)]
+    durs = {}
+    for enc in ("fp32", "f16x3", "bf16"):
+        model = FeedForwardTransformer(80, 80, use_scaled_pos_enc=True, **kw)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        model.eval().cuda().set_precision("bf16", enc)
+        pk = model.infer_batch(xs)["packed"]
+        durs[enc] = pk["durations"].cpu().numpy()
+        if enc == "f16x3":
+            logd = pk["log_durations"].cpu().numpy()
+    assert np.array_equal(durs["f16x3"], durs["fp32"])
+    assert 0 < (durs["bf16"] != durs["fp32"]).sum() < 0.05 * durs["fp32"].size
+    cfg = fs2_oracle.full_cfg(80, 80, use_scaled_pos_enc=True, **kw)
+    sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    cu = np.concatenate([[0], np.cumsum([len(x) for x in xs])])
+    worst = 0.0
+    for b in (0, 9, 20, 31):
+        o = fs2_oracle.infer_one(sd_t, cfg, xs[b])
+        assert np.array_equal(durs["f16x3"][cu[b]:cu[b + 1]], o["durations"].numpy())
+        worst = max(worst, np.abs(logd[cu[b]:cu[b + 1]] - o["log_durations"].numpy()).max())
+    assert worst <= 5e-6, worst          # fp32 summation-order noise level (measured 1e-6; bf16 encoder: 4e-3)
+
+
 @pytest.mark.parametrize("name", helpers.TRAIN_CASES)
 def test_training_forward_loss_matches_reference(name):
     z, meta = helpers.load_golden(name)
