@@ -64,15 +64,34 @@ template <typename T> __device__ __forceinline__ void store4(T* dst, const f32x4
 struct __attribute__((aligned(16))) vec16 { uint32_t x, y, z, w; };
 
 // ---- wave reductions -------------------------------------------------------------------
+// DPP forms (VALU only): a Hillis-Steele scan inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals
+// carried across the four rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): lane 63 ends with
+// the reduction over all 64 lanes, read back as a wave-uniform value.  The __shfl_xor butterfly they replace is six
+// ds_bpermute round trips through the CU's LDS pipe per reduction, which is what bounded the one-wave-per-row
+// LayerNorm kernels (layernorm_rowdot with a 4-wide head: 21.8 -> us per 24.7 k rows, tools/bench_hbm_kernels.py).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_src(float v, float fill) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), CTRL,
+                                                                  ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_src<0x111, 0xF>(v, 0.f);     // row_shr:1 (lanes without a source take the fill value)
+    v += dpp_src<0x112, 0xF>(v, 0.f);     // row_shr:2
+    v += dpp_src<0x114, 0xF>(v, 0.f);     // row_shr:4
+    v += dpp_src<0x118, 0xF>(v, 0.f);     // row_shr:8   -> lane 15 of each row: the row's sum
+    v += dpp_src<0x142, 0xA>(v, 0.f);     // row_bcast:15 into rows 1, 3
+    v += dpp_src<0x143, 0xC>(v, 0.f);     // row_bcast:31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float ninf = -__builtin_inff();
+    v = fmaxf(v, dpp_src<0x111, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_src<0x112, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_src<0x114, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_src<0x118, 0xF>(v, ninf));
+    v = fmaxf(v, dpp_src<0x142, 0xA>(v, ninf));
+    v = fmaxf(v, dpp_src<0x143, 0xC>(v, ninf));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- LDS-DMA pipelines that span a barrier ----------------------------------------------------

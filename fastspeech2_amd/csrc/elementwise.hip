@@ -168,7 +168,86 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
 // energy predictors at frame level, where that fp32 matrix (M x 384) was written only to be read once by
 // rowdot_kernel.  Same arithmetic in the same order as add_layernorm_kernel + rowdot_kernel.  Inference only (the
 // training step keeps the LayerNorm output for the head's weight gradient).
+// One wave per LRD_ROWS consecutive rows: the LayerNorm affine and the head's weight rows are loaded once per wave
+// (they were re-read for every row: (2 + NOUT) x C x 4 bytes of L1/L2 traffic per 4 C bytes of HBM), and all rows'
+// loads are issued before the first reduction.
+constexpr int LRD_ROWS = 4;
+
+template <int NOUT>
 __global__ __launch_bounds__(256) void layernorm_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, const float* __restrict__ W,
+                                                               const float* __restrict__ hb, float* __restrict__ out, int M,
+                                                               int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LRD_ROWS;
+    if (row0 >= M) return;
+    const int cv = C >> 2;
+    constexpr int NV = 2;                     // C <= 512 (the entry point sends wider rows to the generic form)
+    f32x4 v[LRD_ROWS][NV];
+#pragma unroll
+    for (int r = 0; r < LRD_ROWS; ++r) {
+        const size_t roff = (size_t)min(row0 + r, M - 1) * C;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = lane + k * 64;
+            v[r][k] = j < cv ? *(const f32x4*)(x + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 ww[NV], bb[NV], wv[NOUT][NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int j = lane + k * 64;
+        const bool ok = j < cv;
+        ww[k] = ok ? *(const f32x4*)(w + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        bb[k] = ok ? *(const f32x4*)(b + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NOUT; ++h)
+            wv[h][k] = ok ? *(const f32x4*)(W + (size_t)h * C + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float hbv[NOUT];
+#pragma unroll
+    for (int h = 0; h < NOUT; ++h) hbv[h] = hb[h];
+#pragma unroll
+    for (int r = 0; r < LRD_ROWS; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + k * 64 < cv) s += (v[r][k][0] + v[r][k][1]) + (v[r][k][2] + v[r][k][3]);
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + k * 64 < cv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = v[r][k][e] - mean;
+                    q += dlt * dlt;
+                }
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+        float acc[NOUT];
+#pragma unroll
+        for (int h = 0; h < NOUT; ++h) acc[h] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            if (lane + k * 64 < cv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[r][k][e] - mean) * rstd * ww[k][e] + bb[k][e];
+#pragma unroll
+                for (int h = 0; h < NOUT; ++h)
+                    acc[h] += (o[0] * wv[h][k][0] + o[1] * wv[h][k][1]) + (o[2] * wv[h][k][2] + o[3] * wv[h][k][3]);
+            }
+#pragma unroll
+        for (int h = 0; h < NOUT; ++h) {
+            const float t = wave_sum(acc[h]);
+            if (lane == 0 && row0 + r < M) out[(size_t)(row0 + r) * NOUT + h] = t + hbv[h];
+        }
+    }
+}
+
+// any C <= 1024, any NOUT <= 8: one wave per row
+__global__ __launch_bounds__(256) void layernorm_rowdot_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ b, const float* __restrict__ W,
                                                                const float* __restrict__ hb, float* __restrict__ out, int M,
                                                                int C, int NOUT, float eps) {
@@ -304,7 +383,11 @@ __global__ __launch_bounds__(1024) void lr_plan_kernel(const int* __restrict__ d
 }
 
 // gather: frame t of utterance b copies phone j = #{ p : cum_b[p] <= t } (zero-duration phones
-// are skipped).  One wave per output frame; the search is wave-uniform, the copy is 16 B/lane.
+// are skipped).  One wave per LRG_FRAMES consecutive output frames: lane l < LRG_FRAMES runs the two binary searches
+// of frame row0 + l (lane-parallel: the ~12 dependent loads are paid once per 16 frames, not per frame) and writes
+// the row tables coalesced; then all 64 lanes copy the rows, 16 B per lane, LRG_FRAMES independent loads in flight.
+constexpr int LRG_FRAMES = 16;
+
 template <typename T>
 __global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict__ hs, const int* __restrict__ cum,
                                                         const int* __restrict__ cu_phone,
@@ -313,29 +396,47 @@ __global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict_
                                                         int2* __restrict__ frame_seg, int* __restrict__ frame_pos,
                                                         int* __restrict__ lr_index, int Mf, int d) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= Mf) return;
-    const int b = find_segment(cu_frames, B, row);
-    const int f0 = cu_frames[b];
-    const int t = row - f0;
-    const int p0 = cu_phone[b], p1 = cu_phone[b + 1];
-    // first phone p in [p0, p1) with cum[p] > t
-    int lo = p0, hi = p1 - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (cum[mid] > t) hi = mid; else lo = mid + 1;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LRG_FRAMES;
+    if (row0 >= Mf) return;
+    int src = 0;
+    {
+        const int row = min(row0 + (lane & (LRG_FRAMES - 1)), Mf - 1);
+        const int b = find_segment(cu_frames, B, row);
+        const int f0 = cu_frames[b];
+        const int t = row - f0;
+        const int p0 = cu_phone[b], p1 = cu_phone[b + 1];
+        // first phone p in [p0, p1) with cum[p] > t
+        int lo = p0, hi = p1 - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        src = lo;
+        if (lane < LRG_FRAMES && row0 + lane < Mf) {
+            frame_seg[row] = make_int2(f0, cu_frames[b + 1]);
+            frame_pos[row] = t;
+            lr_index[row] = lo - p0;
+        }
     }
-    if (lane == 0) {
-        frame_seg[row] = make_int2(f0, cu_frames[b + 1]);
-        frame_pos[row] = t;
-        lr_index[row] = lo - p0;
-    }
-    const float* src = hs + (size_t)lo * d;
     const int dv = d >> 2;
     for (int k = lane; k < dv; k += 64) {
-        const f32x4 v = *(const f32x4*)(src + k * 4);
-        if (out_f32) *(f32x4*)(out_f32 + (size_t)row * d + k * 4) = v;
-        if (out_t) store4<T>(out_t + (size_t)row * d + k * 4, v);
+#pragma unroll
+        for (int r0 = 0; r0 < LRG_FRAMES; r0 += 8) {       // 8 independent row loads in flight per lane
+            f32x4 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int sr = __shfl(src, r0 + r, 64);
+                v[r] = *(const f32x4*)(hs + (size_t)sr * d + k * 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = row0 + r0 + r;
+                if (row < Mf) {
+                    if (out_f32) *(f32x4*)(out_f32 + (size_t)row * d + k * 4) = v[r];
+                    if (out_t) store4<T>(out_t + (size_t)row * d + k * 4, v[r]);
+                }
+            }
+        }
     }
 }
 
@@ -344,8 +445,10 @@ __global__ __launch_bounds__(256) void lr_gather_kernel(const float* __restrict_
 // per-frame affine map, network/variance_adaptor.py:35-51, :203-206), then the decoder's
 // positional encoding (network/encoder.py:216-219).
 // ---------------------------------------------------------------------------------------
+constexpr int VAP_ROWS = 4;     // rows per thread: the embedding weights of its 4 channels stay in registers
+
 template <typename T>
-__global__ void variance_add_posenc_kernel(const float* __restrict__ hs, const float* __restrict__ pitch,
+__global__ __launch_bounds__(256) void variance_add_posenc_kernel(const float* __restrict__ hs, const float* __restrict__ pitch,
                                            const float* __restrict__ energy, const float* __restrict__ Wp,
                                            const float* __restrict__ bp, const float* __restrict__ We,
                                            const float* __restrict__ be, float pscale, float escale,
@@ -356,53 +459,64 @@ __global__ void variance_add_posenc_kernel(const float* __restrict__ hs, const f
     if (alpha_dev) alpha = *alpha_dev;
     const int dv = d >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)M * dv) return;
-    const int m = (int)(idx / dv), c = (int)(idx % dv) * 4;
-    const f32x4 h = *(const f32x4*)(hs + (size_t)m * d + c);
-    const f32x4 pp = *(const f32x4*)(pe + (size_t)pos[m] * d + c);
+    const int m0 = (int)(idx / dv) * VAP_ROWS, c = (int)(idx % dv) * 4;
+    if (m0 >= M) return;
     const f32x4 bpv = *(const f32x4*)(bp + c);
     const f32x4 bev = *(const f32x4*)(be + c);
-    f32x4 pemb = bpv, eemb = bev;
-    if (pdim == 4 && edim == 1) {          // the model's shapes (network/fastspeech2.py:135-136)
-        f32x4 pv = *(const f32x4*)(pitch + (size_t)m * 4);
-        const float ev = energy[m] * escale;
-        const f32x4 wev = *(const f32x4*)(We + c);
+    const bool model_dims = pdim == 4 && edim == 1;          // the model's shapes (network/fastspeech2.py:135-136)
+    f32x4 wp[4], wev = {0.f, 0.f, 0.f, 0.f};
+    if (model_dims) {
+        wev = *(const f32x4*)(We + c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const f32x4 w = *(const f32x4*)(Wp + (size_t)(c + r) * 4);
-            float t = bpv[r];
+        for (int r = 0; r < 4; ++r) wp[r] = *(const f32x4*)(Wp + (size_t)(c + r) * 4);
+    }
+    f32x4 h[VAP_ROWS], pp[VAP_ROWS], pv[VAP_ROWS];
+    float ev[VAP_ROWS];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) t += w[j] * (pv[j] * pscale);
-            pemb[r] = t;
-            eemb[r] = bev[r] + wev[r] * ev;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = bpv[r];
-            for (int j = 0; j < pdim; ++j) t += Wp[(c + r) * pdim + j] * (pitch[(size_t)m * pdim + j] * pscale);
-            pemb[r] = t;
-            float u = bev[r];
-            for (int j = 0; j < edim; ++j) u += We[(c + r) * edim + j] * (energy[(size_t)m * edim + j] * escale);
-            eemb[r] = u;
+    for (int q = 0; q < VAP_ROWS; ++q) {                      // every load of every row is issued before the first use
+        const int m = min(m0 + q, M - 1);
+        h[q] = *(const f32x4*)(hs + (size_t)m * d + c);
+        pp[q] = *(const f32x4*)(pe + (size_t)pos[m] * d + c);
+        if (model_dims) {
+            pv[q] = *(const f32x4*)(pitch + (size_t)m * 4);
+            ev[q] = energy[m] * escale;
         }
     }
-    f32x4 x, v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        x[r] = h[r] + (eemb[r] + pemb[r]);
-        v[r] = x[r] * xscale + alpha * pp[r];
-    }
-    if (hs_va) *(f32x4*)(hs_va + (size_t)m * d + c) = x;
-    if (out_f32) *(f32x4*)(out_f32 + (size_t)m * d + c) = v;
-    if (out_t) {
-        T t4[4];
+    for (int q = 0; q < VAP_ROWS; ++q) {
+        const int m = m0 + q;
+        f32x4 pemb = bpv, eemb = bev;
+        if (model_dims) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t4[r] = from_f32<T>(v[r]);
-        if constexpr (sizeof(T) == 2)
-            *(uint2*)(out_t + (size_t)m * d + c) = *(const uint2*)t4;
-        else
-            *(f32x4*)(out_t + (size_t)m * d + c) = *(const f32x4*)t4;
+            for (int r = 0; r < 4; ++r) {
+                float t = bpv[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t += wp[r][j] * (pv[q][j] * pscale);
+                pemb[r] = t;
+                eemb[r] = bev[r] + wev[r] * ev[q];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = bpv[r];
+                for (int j = 0; j < pdim; ++j) t += Wp[(c + r) * pdim + j] * (pitch[(size_t)min(m, M - 1) * pdim + j] * pscale);
+                pemb[r] = t;
+                float u = bev[r];
+                for (int j = 0; j < edim; ++j) u += We[(c + r) * edim + j] * (energy[(size_t)min(m, M - 1) * edim + j] * escale);
+                eemb[r] = u;
+            }
+        }
+        f32x4 x, v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            x[r] = h[q][r] + (eemb[r] + pemb[r]);
+            v[r] = x[r] * xscale + alpha * pp[q][r];
+        }
+        if (m < M) {
+            if (hs_va) *(f32x4*)(hs_va + (size_t)m * d + c) = x;
+            if (out_f32) *(f32x4*)(out_f32 + (size_t)m * d + c) = v;
+            if (out_t) store4<T>(out_t + (size_t)m * d + c, v);
+        }
     }
 }
 
@@ -618,10 +732,10 @@ extern "C" int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phon
     FS2_CHECK_ARG(B > 0 && d > 0 && d % 4 == 0, "fs2_lr_gather: bad dims");
     if (Mf <= 0) return FS2_OK;
     if (dtype == 1)
-        hipLaunchKernelGGL(lr_gather_kernel<bf16_t>, dim3(blocks_for(Mf, 4)), dim3(256), 0, stream, hs, cum, cu_phone,
+        hipLaunchKernelGGL(lr_gather_kernel<bf16_t>, dim3(blocks_for(Mf, 4 * LRG_FRAMES)), dim3(256), 0, stream, hs, cum, cu_phone,
                            cu_frames, B, out_f32, (bf16_t*)out_t, (int2*)frame_seg, frame_pos, lr_index, Mf, d);
     else
-        hipLaunchKernelGGL(lr_gather_kernel<float>, dim3(blocks_for(Mf, 4)), dim3(256), 0, stream, hs, cum, cu_phone,
+        hipLaunchKernelGGL(lr_gather_kernel<float>, dim3(blocks_for(Mf, 4 * LRG_FRAMES)), dim3(256), 0, stream, hs, cum, cu_phone,
                            cu_frames, B, out_f32, (float*)out_t, (int2*)frame_seg, frame_pos, lr_index, Mf, d);
     FS2_CHECK_LAUNCH("fs2_lr_gather");
     return FS2_OK;
@@ -636,7 +750,7 @@ static int variance_add_entry(const float* hs, const float* pitch, const float* 
                   "fs2_variance_add_posenc: null pointer");
     FS2_CHECK_ARG(d > 0 && d % 4 == 0 && pdim >= 1 && edim >= 1, "fs2_variance_add_posenc: bad dims");
     if (M <= 0) return FS2_OK;
-    const long long n = (long long)M * (d / 4);
+    const long long n = (long long)((M + VAP_ROWS - 1) / VAP_ROWS) * (d / 4);
     if (dtype == 1)
         hipLaunchKernelGGL(variance_add_posenc_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
                            energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, alpha_dev, hs_va, out_f32,
@@ -709,8 +823,16 @@ extern "C" int fs2_layernorm_rowdot(const float* x, const float* w, const float*
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV && nout >= 1 && nout <= 8,
                   "fs2_layernorm_rowdot: C=%d nout=%d unsupported", C, nout);
     if (M <= 0) return FS2_OK;
-    hipLaunchKernelGGL(layernorm_rowdot_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, W, hb, out, M, C, nout,
-                       eps);
+    if (C <= 512 && (nout == 4 || nout == 1)) {        // the model's heads: pitch (4) and energy (1), C = 384
+        const dim3 grid(blocks_for(M, 4 * LRD_ROWS));
+        if (nout == 4)
+            hipLaunchKernelGGL(layernorm_rowdot_kernel<4>, grid, dim3(256), 0, stream, x, w, b, W, hb, out, M, C, eps);
+        else
+            hipLaunchKernelGGL(layernorm_rowdot_kernel<1>, grid, dim3(256), 0, stream, x, w, b, W, hb, out, M, C, eps);
+    } else {
+        hipLaunchKernelGGL(layernorm_rowdot_generic_kernel, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, w, b, W, hb, out,
+                           M, C, nout, eps);
+    }
     FS2_CHECK_LAUNCH("fs2_layernorm_rowdot");
     return FS2_OK;
 }
