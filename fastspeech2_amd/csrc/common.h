@@ -60,6 +60,29 @@ template <typename T> __device__ __forceinline__ void store4(T* dst, const f32x4
         *(f32x4*)dst = *(const f32x4*)t4;
 }
 
+// ---- split-fp16 storage (dtype FS2_F16X3) ----------------------------------------------------------------
+// A value e is kept as two fp16 numbers, hi = fp16(e) and lo = fp16(e - hi): 22 of fp32's 24 significant bits on
+// operands the fp16 matrix pipe can take (csrc/conv_gemm.hip).  Layout: 4 bytes per element like fp32; every aligned
+// run of 32 consecutive elements (128 bytes) holds its 32 hi halves, then its 32 lo halves.  Buffers are 128-byte
+// aligned, so the run and the position inside it follow from the address of the element's 4-byte slot alone.
+struct f16pair_t { _Float16 h, l; };          // element tag, sizeof == 4 (never read through these members)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <> __device__ __forceinline__ void store4<f16pair_t>(f16pair_t* dst, const f32x4& v) {
+    const uintptr_t a = (uintptr_t)dst;
+    unsigned char* run = (unsigned char*)(a & ~(uintptr_t)127);
+    const int off = (int)(a & 127) >> 1;           // 2 bytes per hi half; `dst` is 16-byte aligned -> off in {0, 8, .., 56}
+    f16x4 hi, lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const _Float16 h = (_Float16)v[r];
+        hi[r] = h;
+        lo[r] = (_Float16)(v[r] - (float)h);       // exact difference, then rounded to fp16
+    }
+    *(f16x4*)(run + off) = hi;
+    *(f16x4*)(run + 64 + off) = lo;
+}
+
 // 16-byte vector copy helpers
 struct __attribute__((aligned(16))) vec16 { uint32_t x, y, z, w; };
 

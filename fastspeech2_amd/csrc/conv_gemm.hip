@@ -56,20 +56,14 @@ struct ConvGemmArgs {
 // ---- f16x3: error-compensated half-precision operands (dtype FS2_F16X3) ---------------------------------------
 // x = xh + xl and w = wh + wl with all four terms fp16 (11 significant bits each, so a pair carries 22 of fp32's
 // 24); the product is accumulated as  wh.xh + wh.xl + wl.xh  on the f16 matrix pipe (fp32 accumulate): the dropped
-// term wl.xl and the split residuals are below 2^-21 of |w||x|.  X arrives as fp32 and is split in registers (one
-// split per fragment, re-used by the NT or MT products it takes part in); W is split once at pack time: a 32-channel
-// chunk of a W row is 128 bytes = [32 x hi][32 x lo], the same bytes per row and chunk as fp32, so staging, swizzle
-// and the LDS geometry are those of the fp32 path.  3 MFMAs of 16 cycles against 8 of 32 for exact-fp32 MFMA.
+// term wl.xl and the split residuals are below 2^-21 of |w||x|.  Both operands arrive ALREADY split, in the
+// split-fp16 storage of common.h (f16pair_t): a 32-channel chunk of a row is 128 bytes = [32 x hi][32 x lo], the same
+// bytes per row and chunk as fp32, so staging, swizzle and the LDS geometry are those of the fp32 path and a fragment
+// is two 16-byte LDS reads.  W is split once at pack time, X by the kernel that produced it (LayerNorm T copy, this
+// kernel's own epilogue, fs2_cast): a first version split X in registers here and spent more issue cycles on the
+// conversions than on the MFMAs (77 us per phone-level FFN conv whatever the tile).  3 MFMAs of 16 cycles against
+// 8 of 32 for exact-fp32 MFMA.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split_f16(const f32x8& x, f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)x[j];
-        hi[j] = h;
-        lo[j] = (_Float16)(x[j] - (float)h);       // exact difference (<= 13 significant bits), then rounded to fp16
-    }
-}
 __device__ __forceinline__ f32x4 mma16_f16(const f16x8& a, const f16x8& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
@@ -88,7 +82,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 // ---- epilogue (both kernels): lane (g, i) holds token m = mrow0 + 16 mt + i, channels nb .. nb + 4 NT - 1 with
 //      acc[mt][nt][r] <-> channel nb + 4 nt + r.  Loads are issued in batches (clamped addresses, predicated
 //      use) so their latencies overlap.
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float* bias, f32x4 (&acc)[MT][NT], int mrow0,
                                               int nb) {
     const int i = threadIdx.x & 15;
@@ -158,6 +152,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     if (mok && nok[nt]) *(f32x4*)(o + ncl[nt]) = v[nt];
+            } else if constexpr (SPLIT) {      // split-fp16 storage: the input of the next f16x3 GEMM
+                f16pair_t* o = (f16pair_t*)a.out + mc * a.ldo;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (mok && nok[nt]) store4<f16pair_t>(o + ncl[nt], v[nt]);
             } else {
                 T* o = (T*)a.out + (size_t)blockIdx.y * a.split_stride + mc * a.ldo;
                 if constexpr (sizeof(T) == 2 && (NT % 2) == 0) {
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             frag_t wf[NT], xf[MT];
-            f16x8 wh[SPLIT ? NT : 1], wl[SPLIT ? NT : 1];
+            f16x8 wh[SPLIT ? NT : 1], wl[SPLIT ? NT : 1], xh[SPLIT ? MT : 1], xl[SPLIT ? MT : 1];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int r = wrow_base + 4 * nt;
@@ -383,7 +382,10 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             for (int mt = 0; mt < MT; ++mt) {
                 const int r = xrow_base + mt * 16 + tap;
                 const unsigned char* rowp = xs + r * CG_ROWB;
-                if constexpr (sizeof(T) == 2) {
+                if constexpr (SPLIT) {
+                    xh[mt] = *(const f16x8*)(rowp + ((g ^ swz_x(r)) << 4));
+                    xl[mt] = *(const f16x8*)(rowp + (((4 + g) ^ swz_x(r)) << 4));
+                } else if constexpr (sizeof(T) == 2) {
                     xf[mt] = *(const frag_t*)(rowp + (((ks * 4 + g) ^ swz_x(r)) << 4));
                 } else {
                     const f32x4 v0 = *(const f32x4*)(rowp + (((2 * g) ^ swz_x(r)) << 4));
@@ -394,21 +396,25 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             if (need_mask) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    if (shift < lo[mt] || shift > hi[mt]) xf[mt] = frag_zero<T>();
+                    if (shift < lo[mt] || shift > hi[mt]) {
+                        if constexpr (SPLIT) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { xh[mt][j] = (_Float16)0.f; xl[mt][j] = (_Float16)0.f; }
+                        } else {
+                            xf[mt] = frag_zero<T>();
+                        }
+                    }
             }
             if (ks == 0) mid();
             if constexpr (SPLIT) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    f16x8 xh, xl;
-                    split_f16(xf[mt], xh, xl);
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {       // small terms first, then the leading product
-                        acc[mt][nt] = mma16_f16(wl[nt], xh, acc[mt][nt]);
-                        acc[mt][nt] = mma16_f16(wh[nt], xl, acc[mt][nt]);
-                        acc[mt][nt] = mma16_f16(wh[nt], xh, acc[mt][nt]);
+                        acc[mt][nt] = mma16_f16(wl[nt], xh[mt], acc[mt][nt]);
+                        acc[mt][nt] = mma16_f16(wh[nt], xl[mt], acc[mt][nt]);
+                        acc[mt][nt] = mma16_f16(wh[nt], xh[mt], acc[mt][nt]);
                     }
-                }
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
         }
     }
 
-    conv_epilogue<T, MT, NT>(a, bias, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
+    conv_epilogue<T, MT, NT, SPLIT>(a, bias, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
 }
 
 // XCD-aware tile order for a BM x BN tiling (see conv_gemm_kernel); returns the x grid size
@@ -512,7 +518,15 @@ static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
 // Used by the phone-level half only (a few thousand tokens): 64 x 64 tiles when 128 x 128 would leave CUs idle.
 static int dispatch_conv_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
-    if (big_blocks < 200) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
+    static const int forced = getenv("FS2_SPLIT_TILE") ? atoi(getenv("FS2_SPLIT_TILE")) : 0;   // experiments: 22, 24, 42, 44
+    if (forced == 22) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
+    if (forced == 24) return launch_conv_gemm<float, 2, 4, 2, 1, false, 3, 0, true>(a, stream);
+    if (forced == 42) return launch_conv_gemm<float, 4, 2, 2, 1, false, 3, 0, true>(a, stream);
+    if (forced == 44) return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
+    // 128 x 128 tiles down to 64 workgroups: alone, 64-row tiles are up to 15 % faster on these launches (more
+    // workgroups per CU to hide the stage latency), but the phone-level half runs beside the frame-level kernels of the
+    // previous batch, and there the fewer, larger workgroups win (bench step 1.994 vs 2.02 / 2.03 ms, A/B/A/B on one box)
+    if (big_blocks < 64) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
     return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
 }
 
@@ -586,8 +600,13 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
                   CG_MAX_TAPS);
     FS2_CHECK_ARG(taps == 1 || seg, "fs2_conv_gemm: taps>1 needs the per-row segment table");
     FS2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2, "fs2_conv_gemm: dtype=%d", dtype);
-    FS2_CHECK_ARG(dtype != 2 || (Cin % 32 == 0 && !gate && !drop.thresh && w_scale > 0.f),
-                  "fs2_conv_gemm(f16x3): Cin=%d must be a multiple of 32 (whole [hi | lo] chunks); no gate / dropout", Cin);
+    FS2_CHECK_ARG(dtype != 2 || (Cin % 32 == 0 && ldx % 32 == 0 && !gate && !drop.thresh && w_scale > 0.f &&
+                                 ((uintptr_t)X & 127) == 0 && ((uintptr_t)W & 127) == 0),
+                  "fs2_conv_gemm_f16x3: Cin=%d / ldx=%d must be multiples of 32 (whole [hi | lo] runs), X and W 128-byte "
+                  "aligned; no gate / dropout", Cin, ldx);
+    FS2_CHECK_ARG(dtype != 2 || out_f32 || (ksplit == 1 && !res && N % 32 == 0 && ldo % 32 == 0 && ((uintptr_t)out & 127) == 0),
+                  "fs2_conv_gemm_f16x3: a split-fp16 output needs N=%d / ldo=%d in multiples of 32, 128-byte alignment, no "
+                  "residual and no split-K", N, ldo);
     FS2_CHECK_ARG(relu >= 0 && relu <= 2, "fs2_conv_gemm: activation code %d (0 none, 1 relu, 2 tanh)", relu);
     const int epv = dtype == 1 ? 8 : 4;
     FS2_CHECK_ARG(Cin % epv == 0 && ldx % epv == 0 && ldx >= Cin,
@@ -667,13 +686,14 @@ extern "C" int fs2_conv_gemm(const void* X, const void* W, const float* bias, co
                            ksplit, split_stride, fs2_make_dropout(0, 0, 0.f), stream);
 }
 
-// fs2_conv_gemm in the f16x3 mode: X fp32 [M, ldx], W packed by fs2_pack_weight_f16x3 (values multiplied by the
-// power of two w_scale before the split), out fp32.  Same tiling, masking and epilogue as fs2_conv_gemm.
+// fs2_conv_gemm in the f16x3 mode: X [M, ldx] in split-fp16 storage, W packed by fs2_pack_weight_f16x3 (values
+// multiplied by the power of two w_scale before the split), out fp32 (out_f32 != 0) or split-fp16 storage.  Same
+// tiling, masking and epilogue as fs2_conv_gemm.
 extern "C" int fs2_conv_gemm_f16x3(const void* X, const void* W, float w_scale, const float* bias, const float* res,
                                    void* out, const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo,
-                                   int relu, int ksplit, long long split_stride, hipStream_t stream) {
-    return conv_gemm_entry(X, W, bias, res, nullptr, 1.f, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, 1, 2, ksplit,
-                           split_stride, fs2_make_dropout(0, 0, 0.f), stream, w_scale);
+                                   int relu, int out_f32, int ksplit, long long split_stride, hipStream_t stream) {
+    return conv_gemm_entry(X, W, bias, res, nullptr, 1.f, out, seg, M, N, Cin, taps, ldx, ldr, 0, ldo, relu, out_f32, 2,
+                           ksplit, split_stride, fs2_make_dropout(0, 0, 0.f), stream, w_scale);
 }
 
 // Training forward of a conv / linear followed by dropout: out = dropout(act(conv(X) + bias)) (no residual, no split-K).

@@ -564,6 +564,12 @@ __global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, 
     if (idx < n) dst[idx] = from_f32<T>(src[idx]);
 }
 
+// fp32 -> split-fp16 storage (common.h: f16pair_t), four elements per thread
+__global__ void cast_f16pair_kernel(const float* __restrict__ src, f16pair_t* __restrict__ dst, long long n4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n4) store4<f16pair_t>(dst + idx * 4, *(const f32x4*)(src + idx * 4));
+}
+
 // f16x3 weight operand (csrc/conv_gemm.hip): src (N, C, k) fp32 in nn.Conv1d / nn.Linear layout ->
 // dst[t][n][C / 32][2][32] fp16 = per 32-channel chunk 32 x hi then 32 x lo of  w * scale,  hi = fp16(w * scale),
 // lo = fp16(w * scale - hi).  One thread per (n, c).
@@ -648,7 +654,12 @@ static int add_layernorm_entry(const float* x, const float* parts, int nparts, l
     FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "fs2_add_layernorm: C=%d unsupported (multiple of 4, <= %d)",
                   C, 256 * LN_MAXV);
     if (M <= 0) return FS2_OK;
-    if (dtype == 1)
+    if (dtype == 2) {          // T copy in split-fp16 storage (the GEMM input of the f16x3 phone-level half)
+        FS2_CHECK_ARG(!out_t || (C % 32 == 0 && ((uintptr_t)out_t & 127) == 0),
+                      "fs2_add_layernorm(f16x3): C=%d must be a multiple of 32 and out_t 128-byte aligned", C);
+        hipLaunchKernelGGL(add_layernorm_kernel<f16pair_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
+                           part_stride, w, b, sum_out, out_f32, (f16pair_t*)out_t, M, C, eps, dparts, dout);
+    } else if (dtype == 1)
         hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
                            part_stride, w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps, dparts, dout);
     else
@@ -807,7 +818,11 @@ extern "C" int fs2_pack_padded(const float* src, const int* cu, float* dst, int 
 extern "C" int fs2_cast(const float* src, void* dst, long long n, int dtype, hipStream_t stream) {
     FS2_CHECK_ARG(src && dst && n >= 0, "fs2_cast: bad args");
     if (n == 0) return FS2_OK;
-    if (dtype == 1)
+    if (dtype == 2) {
+        FS2_CHECK_ARG(n % 32 == 0 && ((uintptr_t)dst & 127) == 0 && ((uintptr_t)src & 15) == 0,
+                      "fs2_cast(f16x3): n must be a multiple of 32, dst 128-byte aligned");
+        hipLaunchKernelGGL(cast_f16pair_kernel, dim3(blocks_for(n / 4, 256)), dim3(256), 0, stream, src, (f16pair_t*)dst, n / 4);
+    } else if (dtype == 1)
         hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
     else
         hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, src, (float*)dst, n);

@@ -151,7 +151,7 @@ class Engine:
             raise ValueError("dtype must be 'fp32' or 'bf16' (f16x3 is a phone-level option: encoder_dtype)")
         self.dec_code = hip.DTYPE_CODE[dtype]
         enc_gemm = hip.DTYPE_CODE[encoder_dtype or dtype]
-        self.enc_code = F32 if enc_gemm == hip.F16X3 else enc_gemm       # storage type of phone-level activations
+        self.enc_code = enc_gemm          # type of the phone-level GEMM inputs ("T copies"); F16X3 = split-fp16 storage
         self.dtype, self.encoder_dtype = dtype, (encoder_dtype or dtype)
         d = cfg["adim"]
         self.d, self.h = d, cfg["aheads"]
@@ -243,11 +243,12 @@ class Engine:
         wscale = getattr(w, "fs2_scale", None)
         if tag is not None and self.profile is not None:
             tag = "%s:%s" % (tag, "f16x3" if wscale is not None else ("bf16" if code != F32 else "fp32"))
+        assert (wscale is not None) == (code == hip.F16X3), "f16x3 activations go with f16x3-packed weights"
         with self._timed(tag, "flop", 2.0 * M * N * Cin * taps):
-            if wscale is not None:          # split-fp16 operand (pack_gemm_weight): fp32 in, fp32 out
-                assert code == F32 and int(relu) in (0, 1)
+            if wscale is not None:          # split-fp16 operands (pack_gemm_weight / T copies of code F16X3)
+                assert code == hip.F16X3 and int(relu) in (0, 1)
                 call("fs2_conv_gemm_f16x3", ptr(x), ptr(w), wscale, ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin,
-                     taps, Cin, N, N, int(relu), ksplit, M * N, stream())
+                     taps, Cin, N, N, int(relu), int(out_f32), ksplit, M * N, stream())
             else:
                 call("fs2_conv_gemm", ptr(x), ptr(w), ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps,
                      Cin, N, N, int(relu), int(out_f32), code, ksplit, M * N, stream())
@@ -280,15 +281,20 @@ class Engine:
                 pend = None
             else:
                 a_t = xt
-            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv")
+            split = code == hip.F16X3       # f16x3 half: fp32 q/k/v, fp32 attention, context re-split for the GEMM
+            ac = F32 if split else code
+            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv", out_f32=split)
             if attn_dump is not None:
-                attn_dump.append(self._dump_attention(qkv, lens, code))
-            ctx = self._empty((M, d), code)
+                attn_dump.append(self._dump_attention(qkv, lens, ac))
+            ctx = self._empty((M, d), ac)
             prof = self.profile is not None and lens is not None
-            with self._timed("attention:" + ("fp32" if code == F32 else "bf16") if prof else None, "flop",
+            with self._timed("attention:" + ("fp32" if ac == F32 else "bf16") if prof else None, "flop",
                              4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
-                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, code,
+                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, ac,
                      stream())
+            if split:
+                ctx32, ctx = ctx, self._empty((M, d), code)
+                call("fs2_cast", ptr(ctx32), ptr(ctx), M * d, code, stream())
             if st.concat_after:
                 att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
                 pend = self._empty((2, M, d), dtype=torch.float32)
@@ -381,8 +387,11 @@ class Engine:
         enc_post = not self.enc.pre_ln
         x32 = self._empty((Mp, d), dtype=torch.float32)
         xt = self._empty((Mp, d), ec) if (enc_post and ec != F32) else None
+        split = ec == hip.F16X3
         call("fs2_embed_posenc", ptr(ids), ptr(pos_p), ptr(self.emb), ptr(pe), self.enc_xscale, self.enc_alpha,
-             ptr(x32), ptr(xt), Mp, d, self.idim, ec, stream())
+             ptr(x32), None if split else ptr(xt), Mp, d, self.idim, F32 if split else ec, stream())
+        if split and xt is not None:
+            call("fs2_cast", ptr(x32), ptr(xt), Mp * d, ec, stream())
         if ec == F32:
             xt = x32
         enc_att = [] if want_attention else None

@@ -13,7 +13,7 @@ from . import build as _build
 
 F32, BF16, F16X3 = 0, 1, 2
 DTYPE_CODE = {"fp32": F32, "bf16": BF16, "f16x3": F16X3}
-# storage type of activations: f16x3 keeps fp32 activations (only its GEMM operands are split fp16 pairs)
+# container type of a "T copy": split-fp16 storage is 4 bytes per element (include/fs2_hip.h), held in float32 tensors
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}
 
 
@@ -33,7 +33,7 @@ _SIGNATURES = {
                                     _I, _I, _I, _I, _I, _P],
     "fs2_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_conv_gemm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
-    "fs2_conv_gemm_f16x3": [_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
+    "fs2_conv_gemm_f16x3": [_P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "fs2_pack_weight_f16x3": [_P, _P, _I, _I, _I, _F, _P],
     "fs2_add_layernorm": [_P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -27,7 +27,7 @@ extern "C" {
 
 #define FS2_F32 0
 #define FS2_BF16 1
-#define FS2_F16X3 2   /* fs2_conv_gemm_f16x3 only: fp32 activations, error-compensated fp16 operands (see there) */
+#define FS2_F16X3 2   /* split-fp16 storage (see fs2_conv_gemm_f16x3): T copies of fs2_add_layernorm / fs2_cast, f16x3 GEMMs */
 
 #define FS2_OK 0
 #define FS2_ERR_ARG (-1)
@@ -85,16 +85,19 @@ int fs2_conv_gemm(const void* X, const void* W, const float* bias, const float* 
  * (network/encoder.py:16-30, :39-44, :57-60, :89; network/utils.py:22-36) for the phone-level half, whose output
  * decides the INTEGER durations (network/variance_adaptor.py:128-138): a bf16 GEMM flips ~1 % of them, this mode none
  * on the fixtures (operand error < 2^-21, the level of fp32 summation-order noise).
- * X fp32 [M, ldx]; W from fs2_pack_weight_f16x3 (w * w_scale split into fp16 hi + lo); the kernel splits X into
- * hi + lo in registers and accumulates wl.xh + wh.xl + wh.xh in fp32 (3 MFMAs instead of 8 exact-fp32 ones of
- * twice the cycles); out fp32 [M, ldo] (or split-K partials) = acc / w_scale + bias, act, + res as fs2_conv_gemm.
- * |x| and |w * w_scale| must stay inside the fp16 range (65504).  Cin % 32 == 0. */
+ * Split-fp16 storage (dtype FS2_F16X3 of fs2_cast / fs2_add_layernorm, and this function's X / W / non-fp32 out):
+ * 4 bytes per element; every aligned run of 32 consecutive elements holds 32 fp16 high halves hi = fp16(e), then 32
+ * low halves lo = fp16(e - hi).  Buffers 128-byte aligned, row lengths multiples of 32.
+ * X [M, ldx] split-fp16; W from fs2_pack_weight_f16x3 (w * w_scale); accumulates wl.xh + wh.xl + wh.xh in fp32
+ * (3 MFMAs instead of 8 exact-fp32 ones of twice the cycles); out = acc / w_scale + bias, act, + res as
+ * fs2_conv_gemm, stored as fp32 [M, ldo] / split-K partials (out_f32 != 0) or as split-fp16 (out_f32 == 0: no
+ * residual, no split-K).  |x| and |w * w_scale| must stay inside the fp16 range (65504). */
 int fs2_conv_gemm_f16x3(const void* X, const void* W, float w_scale, const float* bias, const float* res, void* out,
-                        const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int ksplit,
-                        long long split_stride, hipStream_t stream);
+                        const int* seg, int M, int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int out_f32,
+                        int ksplit, long long split_stride, hipStream_t stream);
 
 /* Weight operand of fs2_conv_gemm_f16x3 from the parameter's own layout src (N, C, k) fp32:
- * dst[t][n][C / 32][2][32] fp16 (per 32-channel chunk: 32 x hi, 32 x lo of w * scale; 4 bytes per weight).
+ * dst[t][n][C / 32][2][32] fp16 (split-fp16 storage of w * scale along C).
  * scale: a power of two that brings max |w| near 2^13 (the fp16 low halves then stay normal numbers). */
 int fs2_pack_weight_f16x3(const float* src, void* dst, int N, int C, int k, float scale, hipStream_t stream);
 
@@ -165,7 +168,7 @@ int fs2_unpack_padded(const float* src, const int* cu, float* dst, int B, int Tm
 int fs2_pack_padded(const float* src, const int* cu, float* dst, int B, int Tmax, int C, int M,
                     hipStream_t stream);
 
-/* fp32 -> T copy (weight packing). */
+/* fp32 -> T copy (weight packing; dtype FS2_F16X3: split-fp16 storage, n % 32 == 0). */
 int fs2_cast(const float* src, void* dst, long long n, int dtype, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------

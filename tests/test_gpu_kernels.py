@@ -140,7 +140,7 @@ def test_conv_gemm_frame_level_shapes(cin, n, ksplit, lens):
     (9, 256, 1024, [120, 61, 1, 3, 700], 1),        # phone-level first FFN conv (64 x 64 tiles)
     (9, 1024, 256, [130, 9, 4000], 3),              # second FFN conv, three K ranges, 128 x 128 tiles
     (1, 256, 768, [77, 300], 1),                    # QKV projection
-    (3, 96, 64, [30, 9], 1),                        # odd small shapes (Cin = 3 chunks of 32, N < tile)
+    (3, 96, 64, [30, 9], 1),                        # odd small shapes (Cin = 3 runs of 32, N < tile)
 ])
 def test_conv_gemm_f16x3_is_fp32_grade(taps, cin, n, lens, ksplit):
     """fs2_conv_gemm_f16x3 (error-compensated fp16 operands) against the fp64 convolution of the UNROUNDED fp32
@@ -161,7 +161,9 @@ def test_conv_gemm_f16x3_is_fp32_grade(taps, cin, n, lens, ksplit):
     ref = torch.cat(outs, 0)
     _, _, seg, _ = _seg_tables(lens)
     from fastspeech2_amd.engine import pack_gemm_weight
-    xd, bd, rd = x.to(DEV).contiguous(), b.to(DEV), res.to(DEV)
+    x32, bd, rd = x.to(DEV).contiguous(), b.to(DEV), res.to(DEV)
+    xd = torch.empty_like(x32)                          # split-fp16 storage of X (4 bytes per element)
+    call("fs2_cast", ptr(x32), ptr(xd), M * cin, hip.F16X3, stream())
     wd = pack_gemm_weight(w.to(DEV), hip.F16X3)
     scale = wd.fs2_scale
     assert scale >= 1.0 and math.log2(scale) == int(math.log2(scale))
@@ -171,21 +173,28 @@ def test_conv_gemm_f16x3_is_fp32_grade(taps, cin, n, lens, ksplit):
         for relu, use_res in [(0, False), (1, False), (0, True)]:
             out = torch.full((M, n), float("nan"), device=DEV)
             call("fs2_conv_gemm_f16x3", ptr(xd), ptr(wd), scale, ptr(bd), ptr(rd) if use_res else None, ptr(out), sg, M, n,
-                 cin, taps, cin, n, n, relu, 1, 0, stream())
+                 cin, taps, cin, n, n, relu, 1, 1, 0, stream())
             exp = ref.clamp_min(0) if relu else ref
             exp = exp + res.double() if use_res else exp
             err = (out.cpu().double() - exp).abs().max().item()
             assert err <= 4e-6 * big, (relu, use_res, err)
+        if n % 32 == 0:      # split-fp16 output (what the next f16x3 GEMM reads): hi + lo must give the fp32 result back
+            pairs = torch.full((M, n), float("nan"), device=DEV)
+            call("fs2_conv_gemm_f16x3", ptr(xd), ptr(wd), scale, ptr(bd), None, ptr(pairs), sg, M, n, cin, taps, cin, n, n,
+                 1, 0, 1, 0, stream())
+            h = pairs.cpu().view(torch.float16).view(M, n // 32, 2, 32).float()
+            got = (h[:, :, 0] + h[:, :, 1]).reshape(M, n).double()
+            assert (got - ref.clamp_min(0)).abs().max().item() <= 4e-6 * big
     else:
         parts = torch.full((ksplit, M, n), float("nan"), device=DEV)
         call("fs2_conv_gemm_f16x3", ptr(xd), ptr(wd), scale, ptr(bd), None, ptr(parts), sg, M, n, cin, taps, cin, n, n, 0,
-             ksplit, M * n, stream())
+             1, ksplit, M * n, stream())
         err = (parts.double().sum(0).cpu() - ref).abs().max().item()
         assert err <= 4e-6 * big, err
     # the exact-fp32 path on the same data, for scale
     w32 = w.permute(2, 0, 1).to(DEV).contiguous()
     out = torch.empty((M, n), device=DEV)
-    call("fs2_conv_gemm", ptr(xd), ptr(w32), ptr(bd), None, ptr(out), sg, M, n, cin, taps, cin, n, n, 0, 1, hip.F32, 1, 0, stream())
+    call("fs2_conv_gemm", ptr(x32), ptr(w32), ptr(bd), None, ptr(out), sg, M, n, cin, taps, cin, n, n, 0, 1, hip.F32, 1, 0, stream())
     assert (out.cpu().double() - ref).abs().max().item() <= 4e-6 * big
 
 
