@@ -166,8 +166,12 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
                     s[t][nt][r] = v;
                     m_loc = fmaxf(m_loc, v);
                 }
+#ifdef FS2_ATTN_BPERMUTE
             m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 16, 64));
             m_loc = fmaxf(m_loc, __shfl_xor(m_loc, 32, 64));
+#else
+            m_loc = rows_max(m_loc);
+#endif
             const float m_new = fmaxf(m_run[t], m_loc);     // finite: every tile has >= 1 valid key
             const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);   // v_exp_f32: exp2(-inf) = 0
             m_run[t] = m_new;
@@ -247,8 +251,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float l = l_part[t];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = rows_sum(l);
         const float inv = 1.0f / l;
         if (a.lse && g == 0 && qrow[t] < len) a.lse[(size_t)h * a.M + r0 + qrow[t]] = m_run[t] + __log2f(l);
         if (qrow[t] < len) {

@@ -117,6 +117,34 @@ __device__ __forceinline__ float wave_max(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// reductions over the four lanes {i, i + 16, i + 32, i + 48} (the four 16-lane rows), result in all of them: two
+// v_permlane swaps (VALU) instead of two ds_bpermute round trips, whose s_waitcnt lgkmcnt would also wait for every
+// LDS read the wave has in flight.  swap32(a, a) = {lo, lo} / {hi, hi}; swap16(a, a) = {r0, r0, r2, r2} / {r1, r1, r3, r3}.
+// Issued from inline asm: with the builtins (__builtin_amdgcn_permlane32_swap / 16_swap) hipcc of ROCm 7.2 used the
+// FIRST result register for both results whenever the pair was consumed by one add / max (it emitted
+// `v_permlane32_swap v20, v16; v_add_f32 v20, v20, v20`; tools/microbench/rows_probe.hip reproduces it).  The s_nops
+// are the wait states hipcc would have inserted around a VALU-written operand of these instructions.
+__device__ __forceinline__ void lane_swap32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap16(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rows_max(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);
+    a = b = fmaxf(a, b);
+    lane_swap16(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);
+    a = b = a + b;
+    lane_swap16(a, b);
+    return a + b;
+}
+
 // ---- LDS-DMA pipelines that span a barrier ----------------------------------------------------
 // `s_waitcnt vmcnt(N)` retires all but this wave's N youngest vector-memory instructions, then a raw s_barrier
 // (a __syncthreads() would wait vmcnt(0) and drain every LDS-DMA still in flight).

@@ -83,10 +83,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
 //      acc[mt][nt][r] <-> channel nb + 4 nt + r.  Loads are issued in batches (clamped addresses, predicated
 //      use) so their latencies overlap.
 template <typename T, int MT, int NT, bool SPLIT = false>
-__device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float* bias, f32x4 (&acc)[MT][NT], int mrow0,
-                                              int nb) {
+__device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float* bias, const float* res,
+                                              f32x4 (&acc)[MT][NT], int mrow0, int nb) {
     const int i = threadIdx.x & 15;
-    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldo & 3) == 0) && (!a.res || (a.ldr & 3) == 0) &&
+    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldo & 3) == 0) && (!res || (a.ldr & 3) == 0) &&
                         (!a.gate || (a.ldg & 3) == 0);
     if (vec_ok) {
         bool nok[NT];
@@ -140,10 +140,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
                     for (int r = 0; r < 4; ++r) v[nt][r] = to_f32(g4[r]) > 0.f ? v[nt][r] * a.gate_scale : 0.f;
                 }
             }
-            if (a.res) {
+            if (res) {
                 f32x4 rv[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) rv[nt] = *(const f32x4*)(a.res + mc * a.ldr + ncl[nt]);
+                for (int nt = 0; nt < NT; ++nt) rv[nt] = *(const f32x4*)(res + mc * a.ldr + ncl[nt]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) v[nt] += rv[nt];
             }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
                     if (a.relu == 2) s = tanhf(s);
                     if (a.drop.thresh) s *= drop_mul(a.drop, (uint32_t)m, (uint32_t)n);
                     if (a.gate) s = to_f32(((const T*)a.gate)[(size_t)m * a.ldg + n]) > 0.f ? s * a.gate_scale : 0.f;
-                    if (a.res) s += a.res[(size_t)m * a.ldr + n];
+                    if (res) s += res[(size_t)m * a.ldr + n];
                     const size_t oidx = (size_t)blockIdx.y * a.split_stride + (size_t)m * a.ldo + n;
                     if (a.out_f32)
                         ((float*)a.out)[oidx] = s;
@@ -272,7 +272,8 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     const int chunk_lo = blockIdx.y * cps;
     const int chunk_hi = min(nchunks_all, chunk_lo + cps);
     const int nsteps = max(chunk_hi - chunk_lo, 0) * taps;
-    const float* bias = blockIdx.y == 0 ? a.bias : nullptr;
+    const float* bias = blockIdx.y == 0 ? a.bias : nullptr;      // split-K: bias and residual go into partial 0
+    const float* res = blockIdx.y == 0 ? a.res : nullptr;
 
     const T* __restrict__ X = (const T*)a.X;
     const T* __restrict__ W = (const T*)a.W;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
         }
     }
 
-    conv_epilogue<T, MT, NT, SPLIT>(a, bias, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
+    conv_epilogue<T, MT, NT, SPLIT>(a, bias, res, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
 }
 
 // XCD-aware tile order for a BM x BN tiling (see conv_gemm_kernel); returns the x grid size
@@ -616,8 +617,8 @@ static int conv_gemm_entry(const void* X, const void* W, const float* bias, cons
                       ((uintptr_t)bias & 15) == 0 && ((uintptr_t)res & 15) == 0,
                   "fs2_conv_gemm: pointers must be 16-byte aligned");
     FS2_CHECK_ARG(ksplit >= 1 && ksplit <= 16, "fs2_conv_gemm: ksplit=%d (1..16)", ksplit);
-    FS2_CHECK_ARG(ksplit == 1 || (!relu && !res && split_stride >= (long long)M * ldo && split_stride % 4 == 0),
-                  "fs2_conv_gemm: split-K partial outputs take no relu / residual and need split_stride >= M*ldo");
+    FS2_CHECK_ARG(ksplit == 1 || (!relu && out_f32 && split_stride >= (long long)M * ldo && split_stride % 4 == 0),
+                  "fs2_conv_gemm: split-K partial outputs are fp32, take no activation and need split_stride >= M*ldo");
     if (M == 0) return FS2_OK;
     ConvGemmArgs a;
     a.X = X; a.W = W; a.bias = bias; a.res = res; a.gate = gate; a.ldg = ldg; a.gate_scale = gate_scale; a.drop = drop; a.out = out; a.seg = (const int2*)seg;

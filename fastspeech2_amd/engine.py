@@ -260,7 +260,7 @@ class Engine:
         of = self._empty((M, C), dtype=torch.float32) if (want_f32 or (want_t and code == F32)) else None
         ot = self._empty((M, C), code) if (want_t and code != F32) else None
         nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
-        nbytes = M * C * (4.0 * (1 + nparts) + (4.0 if sum_out is not None else 0.0) + (4.0 if of is not None else 0.0) +
+        nbytes = M * C * (4.0 * ((1 if x is not None else 0) + nparts) + (4.0 if sum_out is not None else 0.0) + (4.0 if of is not None else 0.0) +
                           (2.0 if ot is not None else 0.0))
         with self._timed("add_layernorm" if M > 8192 else None, "byte", nbytes):
             call("fs2_add_layernorm", ptr(x), ptr(parts), nparts, M * C, ptr(w), ptr(b), ptr(sum_out), ptr(of), ptr(ot),
@@ -273,11 +273,17 @@ class Engine:
         GEMM outputs (`pend`, possibly split-K partials); the residual add is done by the LayerNorm
         kernel that needs the sum next (norm1 / norm2 / after_norm)."""
         d, code = self.d, st.code
-        pend = None                       # GEMM output(s) not yet added to the residual stream x32
+        # `pend`: GEMM output(s) that already CONTAIN the residual stream (the GEMM epilogue adds x32 as its `res`
+        # operand — into partial 0 of a split-K launch), waiting for the LayerNorm kernel that needs the sum next
+        # (norm1 / norm2 / after_norm): that kernel then reads only the partials, not x32 as well.
+        pend = None
         for li, L in enumerate(st.layers):
             # ---- self-attention sub-layer (:171-180)
             if st.pre_ln:
-                a_t = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
+                if pend is None:
+                    a_t = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, False, True)[1]
+                else:
+                    a_t = self._ln(None, L["norm1_w"], L["norm1_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
                 pend = None
             else:
                 a_t = xt
@@ -298,27 +304,30 @@ class Engine:
             if st.concat_after:
                 att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
                 pend = self._empty((2, M, d), dtype=torch.float32)
-                self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, out_f32=True, out=pend[0])
+                self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, out_f32=True, out=pend[0], res=x32)
                 self._gemm(att, L["wc_a"], None, M, d, d, 1, code, out_f32=True, out=pend[1])
             else:
-                pend = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, out_f32=True,
+                pend = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, out_f32=True, res=x32,
                                   ksplit=self._ksplit(M, d, d, 1, code), tag="out_proj")
             # ---- position-wise feed-forward sub-layer (:182-187)
             if st.pre_ln:
-                f_t = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
+                f_t = self._ln(None, L["norm2_w"], L["norm2_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
             else:
-                x32, xt = self._ln(x32, L["norm1_w"], L["norm1_b"], M, d, code, True, True, parts=pend)
+                x32, xt = self._ln(None, L["norm1_w"], L["norm1_b"], M, d, code, True, True, parts=pend)
                 f_t = xt
             taps, U = L["taps"], L["units"]
             sg = seg if taps > 1 else None
             hdn = self._gemm(f_t, L["w1"], L["b1"], M, U, d, taps, code, seg=sg, relu=True, tag="ffn1")
-            pend = self._gemm(hdn, L["w2"], L["b2"], M, d, U, taps, code, seg=sg, out_f32=True, tag="ffn2",
+            pend = self._gemm(hdn, L["w2"], L["b2"], M, d, U, taps, code, seg=sg, out_f32=True, tag="ffn2", res=x32,
                               ksplit=self._ksplit(M, d, U, taps, code))
             if not st.pre_ln:
-                x32, xt = self._ln(x32, L["norm2_w"], L["norm2_b"], M, d, code, True, True, parts=pend)
+                x32, xt = self._ln(None, L["norm2_w"], L["norm2_b"], M, d, code, True, True, parts=pend)
                 pend = None
         if st.pre_ln:
-            x32, xt = self._ln(x32, st.after_w, st.after_b, M, d, code, True, True, parts=pend)
+            if pend is None:          # a stack without layers
+                x32, xt = self._ln(x32, st.after_w, st.after_b, M, d, code, True, True)
+            else:
+                x32, xt = self._ln(None, st.after_w, st.after_b, M, d, code, True, True, parts=pend)
         return x32, xt
 
     def _dump_attention(self, qkv, lens, code):

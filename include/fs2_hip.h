@@ -74,6 +74,9 @@ int fs2_add_layernorm(const float* x, const float* parts, int nparts, long long 
  * 0 none, 1 ReLU, 2 tanh (PostNet)
  * X [M,ldx] T; W packed [taps][N][Cin] T; bias fp32 [N] or NULL; res fp32 [M,ldr] or NULL;
  * out [M,ldo] fp32 (out_f32=1) or T.  seg is required when taps > 1.
+ * ksplit > 1: the channel chunks are split into `ksplit` ranges whose fp32 partial results go to
+ * out + p * split_stride (no activation); bias and res are added into partial 0, so the sum of the partials —
+ * taken by fs2_add_layernorm's `parts` — is the full result.
  * Replaces nn.Conv1d in MultiLayeredConv1d (network/encoder.py:16-30) and ConvNorm
  * (network/utils.py:22-36), and nn.Linear in PositionwiseFeedForward / MultiHeadedAttention /
  * feat_out (network/encoder.py:39-44, :57-60, :89; network/fastspeech2.py:158-159, :219). */

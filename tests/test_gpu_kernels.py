@@ -133,6 +133,11 @@ def test_conv_gemm_frame_level_shapes(cin, n, ksplit, lens):
              ksplit, M * n, stream())
         err = (parts.sum(0) - ref).abs().max().item()
         assert err <= 2e-3 * scale, err
+        # with a residual operand: it goes into partial 0 (the engine's `x + sublayer(x)` without a second read of x)
+        call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), ptr(rd), ptr(parts), ptr(seg), M, n, cin, taps, cin, n, n, 0, 1, code,
+             ksplit, M * n, stream())
+        err = (parts.sum(0) - (ref + rd)).abs().max().item()
+        assert err <= 2e-3 * scale, err
     torch.cuda.synchronize()
 
 

@@ -1,0 +1,28 @@
+"""fs2_attention alone at the BASELINE decoder shapes (config 2: 32 utterances of ~800 frames; config 4: one / four
+utterances of ~4100 frames), bf16 and fp32, random data, interleaved rounds."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from fastspeech2_amd import hip, synth
+from fastspeech2_amd.hip import call, ptr, stream
+from tools.bench_kernels import timeit
+
+DEV = "cuda:0"
+h, dk = 2, 128
+d = h * dk
+rng = np.random.Generator(np.random.PCG64(0))
+cases = [("config 2 decoder", np.clip(np.rint(rng.normal(800, 100, 32)), 400, 1200).astype(int).tolist()),
+         ("config 2 encoder", np.clip(np.rint(rng.normal(120, 15, 32)), 60, 180).astype(int).tolist()),
+         ("config 4 B=1", [4165]), ("config 4 B=4", [4165, 4100, 3900, 4000])]
+for dtype in (sys.argv[1:] or ["bf16", "fp32"]):
+    code, tdt = hip.DTYPE_CODE[dtype], hip.TORCH_DTYPE[hip.DTYPE_CODE[dtype]]
+    for name, lens in cases:
+        M = sum(lens)
+        cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device=DEV)
+        qkv = torch.randn(M, 3 * d, device=DEV).to(tdt)
+        ctx = torch.empty(M, d, device=DEV, dtype=tdt)
+        def fn():
+            call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu), len(lens), max(lens), h, dk, 3 * d, d, code, stream())
+        med, mn = timeit(fn)
+        fl = 4.0 * d * sum(float(n) * n for n in lens)
+        print("%-5s %-18s M=%6d  %8.1f us (min %8.1f)  %7.1f TFLOP/s" % (dtype, name, M, med, mn, fl / med / 1e6), flush=True)
