@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="no cross-step overlap: one forward after the other")
     ap.add_argument("--frame-streams", type=int, default=3, help="alternate the frame-level halves over this many streams")
+    ap.add_argument("--phone-group", type=int, default=2,
+                    help="run the phone-level half of this many consecutive steps as one ragged batch (Engine.forward_pipelined)")
     ap.add_argument("--no-pure", action="store_true", help="skip the extra timed loop with the phone-level half in --dtype")
     ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
     ap.add_argument("--force-dist", action="store_true",
@@ -197,7 +199,7 @@ def main():
         else:
             last = collections.deque(maxlen=len(feed))     # keep only the last step's outputs alive
             for o in eng.forward_pipelined((feed[j % len(feed)] for j in range(n * len(feed))),
-                                           frame_streams=args.frame_streams):
+                                           frame_streams=args.frame_streams, phone_group=args.phone_group):
                 last.append(o)
             last = list(last)
         return last
@@ -330,7 +332,7 @@ def main():
                        "durations": ("bit-exact vs the fp32 engine and the reference goldens (tests/test_gpu_model.py)"
                                      if args.encoder_dtype != "bf16" else "~1 % differ by one frame (bf16 encoder)"),
                        "pure_%s" % args.dtype: pure,
-                       "step_overlap": "none" if args.serial else "phone-level half of step k+1 on a side stream under the frame-level half of step k; frame-level halves alternate over %d stream(s)" % args.frame_streams,
+                       "step_overlap": "none" if args.serial else "phone-level halves of the next %d step(s) as one ragged batch on a side stream under the frame-level halves of the current ones; frame-level halves alternate over %d stream(s)" % (args.phone_group, args.frame_streams),
                        "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
                        "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4)},

@@ -438,10 +438,14 @@ class Engine:
                 t.record_stream(cur)
         ctx["done"].synchronize()
         cu_f = ctx["cu_host"].numpy()
+        cu_phone, cu_frames, hs32, cum = ctx["cu_phone"], ctx["cu_frames"], ctx["hs32"], ctx["cum"]
+        if "cu_slice" in ctx:                   # one batch of a grouped phone phase: rebase the frame offsets
+            u0, u1 = ctx["cu_slice"]
+            cu_f = cu_f[u0:u1 + 1] - cu_f[u0]
+            cu_frames = cu_frames[u0:u1 + 1] - cu_frames[u0:u0 + 1]
         olens = np.diff(cu_f).astype(np.int64).tolist()
         Mf = int(cu_f[-1])
         max_ol = max(olens) if B else 0
-        cu_phone, cu_frames, hs32, cum = ctx["cu_phone"], ctx["cu_frames"], ctx["hs32"], ctx["cum"]
 
         dc = self.dec_code
         hs_lr32 = self._empty((Mf, d), dtype=torch.float32)
@@ -495,14 +499,18 @@ class Engine:
             out["enc_attention"], out["dec_attention"] = ctx["enc_att"], dec_att
         return out
 
-    def forward_pipelined(self, batches, frame_streams: int = 1, **kw):
+    def forward_pipelined(self, batches, frame_streams: int = 1, phone_group: int = 1, **kw):
         """Throughput mode for a stream of batches [(ids, ilens), ...]: the phone phase of batch k+1 (small
         grids that cannot fill 256 CUs) runs on a side stream underneath the frame phase of batch k.
         frame_streams > 1 additionally alternates the frame phases over that many streams, so the tail of one
-        batch's kernels overlaps the head of the next batch's.  Same kernels, same results as `forward`;
+        batch's kernels overlaps the head of the next batch's.  phone_group > 1 runs the phone-level half of that
+        many consecutive batches as ONE ragged batch (a few thousand phones per batch leave most CUs with one
+        workgroup; utterances are independent, so grouping changes launch shapes, not results beyond summation
+        order) and hands each batch its slice.  Same kernels as `forward`;
         yields one output dict per batch, in order (outputs of batch k are ordered after the current stream
         only once `out["ready"]` has been waited for when frame_streams > 1; the output tensors are registered with
         the calling stream, so consumers enqueued there after that wait keep them alive)."""
+        import collections
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream(device=self.dev)
             self._fstreams = []
@@ -510,19 +518,46 @@ class Engine:
             self._fstreams.append(torch.cuda.Stream(device=self.dev))
         main = torch.cuda.current_stream()
         it = iter(batches)
+        pending = collections.deque()
+        group = max(1, int(phone_group))
 
-        def launch_phone(b):
+        def refill():
+            """phone phase of the next `group` batches (as one launch sequence) on the side stream"""
+            got = []
+            for _ in range(group):
+                b = next(it, None)
+                if b is None:
+                    break
+                got.append(b)
+            if not got:
+                return False
             self._side.wait_stream(main)       # inputs prepared on the main stream
             with torch.cuda.stream(self._side):
-                return self.phone_phase(b[0], b[1], kw.get("duration_control", 1.0))
-        try:
-            ctx = launch_phone(next(it))
-        except StopIteration:
-            return
+                if len(got) == 1:
+                    pending.append(self.phone_phase(got[0][0], got[0][1], kw.get("duration_control", 1.0)))
+                else:
+                    ids = torch.cat([b[0] for b in got])
+                    ilens = [int(v) for b in got for v in b[1]]
+                    ctx = self.phone_phase(ids, ilens, kw.get("duration_control", 1.0))
+                    u0 = p0 = 0
+                    subs = []
+                    for b in got:
+                        subs.append(self._slice_phone_ctx(ctx, u0, u0 + len(b[1]), p0, p0 + int(sum(b[1]))))
+                        u0 += len(b[1])
+                        p0 += int(sum(b[1]))
+                    done = torch.cuda.Event()          # after the slices' own row-offset copies
+                    done.record()
+                    for sub in subs:
+                        sub["done"] = done
+                    pending.extend(subs)
+            return True
+
+        more = refill()
         k = 0
-        while ctx is not None:
-            nxt = next(it, None)
-            nctx = launch_phone(nxt) if nxt is not None else None
+        while pending:
+            ctx = pending.popleft()
+            if more and len(pending) < group:
+                more = refill()               # the next group's phone phase goes under this batch's frame phase
             if frame_streams > 1:
                 fs = self._fstreams[k % frame_streams]
                 fs.wait_stream(main)
@@ -539,8 +574,22 @@ class Engine:
                 yield out
             else:
                 yield self.frame_phase(ctx, None, None, kw.get("pitch_control", 1.0), kw.get("energy_control", 1.0))
-            ctx = nctx
             k += 1
+
+    @staticmethod
+    def _slice_phone_ctx(ctx, u0, u1, p0, p1):
+        """The part of a grouped phone phase that belongs to utterances [u0, u1) = phone rows [p0, p1): views of the
+        group's tensors; the row offsets are rebased (phone offsets from the host lengths, frame offsets in
+        frame_phase once the group's frame counts have arrived)."""
+        il = ctx["ilens"][u0:u1]
+        cu_p = np.zeros(len(il) + 1, np.int32)
+        cu_p[1:] = np.cumsum(il)
+        sub = dict(ctx)
+        sub.update(B=u1 - u0, Mp=p1 - p0, ilens=il, cu_phone=torch.from_numpy(cu_p).to(ctx["hs32"].device, non_blocking=True),
+                   hs32=ctx["hs32"][p0:p1], cum=ctx["cum"][p0:p1], dur_used=ctx["dur_used"][p0:p1],
+                   dur_pred=ctx["dur_pred"][p0:p1], logd=ctx["logd"][p0:p1], cu_slice=(u0, u1),
+                   enc_att=None if ctx["enc_att"] is None else [a[u0:u1] for a in ctx["enc_att"]])
+        return sub
 
     def unpack(self, packed: torch.Tensor, cu: torch.Tensor, B: int, Tmax: int) -> torch.Tensor:
         """packed [M, C] fp32 -> zero-padded [B, Tmax, C] (pad_list, network/utils.py:50-56)."""

@@ -60,7 +60,8 @@ def decode(cfg, model, current_step=0, criterion=None, rank: int = 0, world_size
         for bucket in buckets:
             xs = [utts[ids[i]] for i in bucket]
             feed.append((torch.from_numpy(np.concatenate(xs)).to(eng.dev), [len(x) for x in xs]))
-        outs = eng.forward_pipelined(feed, frame_streams=2, duration_control=dc, pitch_control=pc, energy_control=ec)
+        outs = eng.forward_pipelined(feed, frame_streams=2, phone_group=2, duration_control=dc, pitch_control=pc,
+                                     energy_control=ec)
         for bucket, out in zip(buckets, outs):
             out["ready"].synchronize()
             mel = out["mel"].cpu().numpy()                                   # after the PostNet (== before without one)

@@ -408,3 +408,15 @@ def test_pipelined_forward_equals_serial():
             assert a["olens"] == b["olens"]
             assert torch.equal(a["durations"], b["durations"])
             assert torch.equal(a["mel"], b["mel"])
+    # phone-level halves of 2 / 3 consecutive batches run as one ragged batch (other launch shapes: fp32 summation
+    # order may differ, the integer results may not)
+    for group in (2, 3):
+        piped = list(eng.forward_pipelined(batches, frame_streams=2, phone_group=group))
+        assert len(piped) == len(serial)
+        for a, b in zip(serial, piped):
+            b["ready"].synchronize()
+            assert a["olens"] == b["olens"]
+            assert torch.equal(a["durations"], b["durations"]) and torch.equal(a["lr_index"], b["lr_index"])
+            assert torch.equal(a["cu_frames"], b["cu_frames"]) and torch.equal(a["cu_phone"], b["cu_phone"])
+            assert (a["mel"] - b["mel"]).abs().max().item() <= 1e-4
+            assert (a["enc_out"] - b["enc_out"]).abs().max().item() <= 1e-4
