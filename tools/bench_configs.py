@@ -20,9 +20,10 @@ def run(eng, xs, iters=20):
     fr = sum(out["olens"])
     return dt * 1e3, fr, fr / dt
 
-for dtype in ("bf16", "fp32"):
-    model, _, _ = bench.build_model(dtype, None, torch.device("cuda", 0))
+for dtype, enc in (("bf16", "f16x3"), ("bf16", "bf16"), ("fp32", "fp32")):
+    model, _, _ = bench.build_model(dtype, enc, torch.device("cuda", 0))
     eng = model.engine()
+    dtype = dtype if enc == dtype else "%s+%s" % (dtype, enc)
     rng = np.random.Generator(np.random.PCG64(0))
     cases = {"config1 B=1 120 phones": [rng.integers(1, 80, size=120)],
              "config4 B=1 512 phones": [rng.integers(1, 80, size=512)],
@@ -30,19 +31,20 @@ for dtype in ("bf16", "fp32"):
              "config2 B=32": synth.synth_utterances(32, 0)}
     for name, xs in cases.items():
         ms, fr, fps = run(eng, xs)
-        print("%-5s %-24s %8.3f ms  frames=%6d  %10.0f frames/s  RTF=%.2e" % (dtype, name, ms, fr, fps, ms * 1e-3 / (fr * bench.HOP_SECONDS)), flush=True)
+        print("%-10s %-24s %8.3f ms  frames=%6d  %10.0f frames/s  RTF=%.2e" % (dtype, name, ms, fr, fps, ms * 1e-3 / (fr * bench.HOP_SECONDS)), flush=True)
 
 # the shipped param/fastspeech.yaml (6+6 linear-FFN blocks, d=384, 4 heads, PostNet 5x256), random init
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer
 from fastspeech2_amd.param.load_param import load_config
-for dtype in ("bf16", "fp32"):
+for dtype, enc in (("bf16", "f16x3"), ("bf16", None), ("fp32", None)):
     cfg = load_config()
     sd = synth.synth_state_dict(80, 80, 1234, dur_bias=float(np.log(7.67)), dur_w_scale=0.2, **cfg)
     model = FeedForwardTransformer(80, 80, **cfg)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     model.eval().cuda()
-    model.set_precision(dtype)
+    model.set_precision(dtype, enc)
     eng = model.engine()
+    dtype = dtype if enc is None else "%s+%s" % (dtype, enc)
     for name, xs in {"yaml B=1 120 phones": [np.random.Generator(np.random.PCG64(0)).integers(1, 80, size=120)],
                      "yaml B=32": synth.synth_utterances(32, 0)}.items():
         ms, fr, fps = run(eng, xs)
