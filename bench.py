@@ -272,7 +272,7 @@ def main():
                          "kernel symbol; timed one forward at a time, i.e. without the cross-batch overlap of the "
                          "throughput loop)" % (args.dtype, "" if args.encoder_dtype != args.dtype else " and the phone-level half"))
         traffic = None     # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        tpath = os.path.join(ROOT, "profiles", "r01_ffn_conv_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_ffn_conv_traffic.json")
         if args.dtype == "bf16" and os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roofline["traffic"] = traffic

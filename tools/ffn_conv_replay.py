@@ -20,7 +20,7 @@ ROUNDS = 3
 
 def main():
     dev = torch.device("cuda", 0)
-    model, _, _ = bench.build_model("bf16", None, dev)
+    model, _, _ = bench.build_model("bf16", "bf16", dev)
     eng = model.engine()
     xs = bench.rank_batch(1, 0)
     ilens = [len(x) for x in xs]
@@ -35,12 +35,16 @@ def main():
         call("fs2_build_seg", ptr(cu), len(ilens), ptr(s), None, M, stream())
         seg[name] = s
     n = 0
+    # round 2: FS2_REPLAY=dec replays the frame-level (decoder) launches only — the launches the bf16 k=9 kernel symbol
+    # serves now that the phone-level half runs on the f16x3 kernel — with the residual operand the engine passes
+    stacks = (("dec", eng.dec, Mf),) if os.environ.get("FS2_REPLAY") == "dec" else (("enc", eng.enc, Mp), ("dec", eng.dec, Mf))
     for _ in range(ROUNDS):
-        for name, st, M in (("enc", eng.enc, Mp), ("dec", eng.dec, Mf)):
+        for name, st, M in stacks:
             for L in st.layers:
                 x = torch.randn(M, d, device=dev).to(torch.bfloat16)
+                r = torch.randn(M, d, device=dev)
                 h = eng._gemm(x, L["w1"], L["b1"], M, L["units"], d, L["taps"], st.code, seg=seg[name], relu=True)
-                eng._gemm(h, L["w2"], L["b2"], M, d, L["units"], L["taps"], st.code, seg=seg[name], out_f32=True,
+                eng._gemm(h, L["w2"], L["b2"], M, d, L["units"], L["taps"], st.code, seg=seg[name], out_f32=True, res=r,
                           ksplit=eng._ksplit(M, d, L["units"], L["taps"], st.code))
                 n += 2
     torch.cuda.synchronize()

@@ -10,6 +10,8 @@ import sys
 def last_conv(dirname, counter, n):
     f = glob.glob(dirname + "/*/*counter_collection.csv")[0]
     rows = [r for r in csv.DictReader(open(f)) if "conv_gemm" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    if len(sys.argv) > 5:                      # kernel-name filter, e.g. Li9E (the k = 9 symbol)
+        rows = [r for r in rows if sys.argv[5] in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     return [float(r["Counter_Value"]) for r in rows[-n:]]
 
