@@ -151,7 +151,7 @@ def cpu_baseline(sd_np, kw, xs, passes):
         for x in xs:
             frames += fs2_oracle.infer_one(sd, cfg, torch.from_numpy(x))["mel"].shape[0]
     dt = time.perf_counter() - t0
-    return dict(value=frames / dt, unit="mel frames/s", cores=threads, kind="port",
+    return dict(value=frames / dt, unit="mel frames/s", cores=threads, host_cpus=os.cpu_count(), kind="port",
                 sample="%d pass(es) over the same 32-utterance batch, fp32 torch-CPU oracle, %.1f s"
                        % (passes, dt))
 
@@ -294,6 +294,13 @@ def main():
             tags = [t for t in tags if t in agg]
             if tags:
                 rooflines[key] = entry(tags, note, mpp)
+        # the k=1 GEMMs move almost as many bytes as they compute on: the same launches against the HBM roof
+        btags = [t + "/bytes" for t in ("qkv:" + d, "out_proj:" + d, "feat_out:" + d) if t + "/bytes" in agg]
+        if btags and "gemm_k1" in rooflines:
+            hb = entry(btags, "")
+            rooflines["gemm_k1"].update(hbm_achieved=hb["achieved"], hbm_unit="GB/s", hbm_frac=hb["frac"],
+                                        bytes_per_launch=hb["bytes_per_launch"],
+                                        note="short-K GEMMs (K = 256): algorithmic bytes X + W + out (+ residual) against 8 TB/s")
 
     # ---- the pure-bf16 figure beside the exact-duration headline (same loop, phone-level half in bf16 too)
     pure = None

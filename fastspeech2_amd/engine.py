@@ -66,8 +66,8 @@ class _Timer:
     """HIP events around one launch on the current stream -> Engine.profile record (tag, kind, work, e0, e1);
     kind "flop": algorithmic FLOPs, "byte": algorithmic HBM bytes."""
 
-    def __init__(self, sink, tag, kind, work):
-        self.sink, self.tag, self.kind, self.work = sink, tag, kind, float(work)
+    def __init__(self, sink, tag, kind, work, nbytes=None):
+        self.sink, self.tag, self.kind, self.work, self.nbytes = sink, tag, kind, float(work), nbytes
 
     def __enter__(self):
         self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -77,6 +77,8 @@ class _Timer:
     def __exit__(self, *exc):
         self.e1.record()
         self.sink.append((self.tag, self.kind, self.work, self.e0, self.e1))
+        if self.nbytes is not None:           # a GEMM that may be HBM-bound: the same interval against its bytes
+            self.sink.append((self.tag + "/bytes", "byte", float(self.nbytes), self.e0, self.e1))
         return False
 
 
@@ -220,10 +222,10 @@ class Engine:
             self._pe = posenc_table(n, self.d).to(self.dev)
         return self._pe
 
-    def _timed(self, tag, kind, work):
+    def _timed(self, tag, kind, work, nbytes=None):
         if self.profile is None or tag is None:
             return _NO_TIMER
-        return _Timer(self.profile, tag, kind, work)
+        return _Timer(self.profile, tag, kind, work, nbytes)
 
     def _empty(self, shape, code=None, dtype=None):
         return torch.empty(shape, device=self.dev, dtype=dtype or hip.TORCH_DTYPE[code])
@@ -244,7 +246,9 @@ class Engine:
         if tag is not None and self.profile is not None:
             tag = "%s:%s" % (tag, "f16x3" if wscale is not None else ("bf16" if code != F32 else "fp32"))
         assert (wscale is not None) == (code == hip.F16X3), "f16x3 activations go with f16x3-packed weights"
-        with self._timed(tag, "flop", 2.0 * M * N * Cin * taps):
+        esz = 2.0 if code == hip.BF16 else 4.0
+        nbytes = M * Cin * esz + taps * N * Cin * esz + ksplit * M * N * (4.0 if out_f32 else esz) + (M * N * 4.0 if res is not None else 0.0)
+        with self._timed(tag, "flop", 2.0 * M * N * Cin * taps, nbytes):
             if wscale is not None:          # split-fp16 operands (pack_gemm_weight / T copies of code F16X3)
                 assert code == hip.F16X3 and int(relu) in (0, 1)
                 call("fs2_conv_gemm_f16x3", ptr(x), ptr(w), wscale, ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin,

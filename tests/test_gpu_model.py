@@ -317,12 +317,26 @@ def test_full_size_properties_bf16():
         assert np.array_equal(lri[cu_f[b]:cu_f[b + 1]], idx)
     assert torch.isfinite(out["mel"]).all()
     # batch row == the same utterance alone.  Not bit-equal: a 1-utterance launch picks other tile /
-    # split-K shapes, i.e. another fp32 summation order, and in bf16 that can flip activation roundings.
+    # split-K shapes, i.e. another fp32 summation order, and in bf16 that can flip activation roundings and, with a
+    # bf16 phone-level half, a duration (then the frames shift and the row cannot be compared).
+    compared = 0
     for b in (0, 13, 31):
         alone = model.infer_batch([xs[b]])
         if np.array_equal(alone["packed"]["durations"].cpu().numpy(), dur[cu_p[b]:cu_p[b + 1]]):
             T = pk["olens"][b]
             assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= BF16_MEL_TOL
+            compared += 1
+    # the throughput mode with exact durations (f16x3 phone-level half): every sampled row MUST be comparable
+    model.set_precision("bf16", "f16x3")
+    out = model.infer_batch(xs)
+    pk = out["packed"]
+    dur = pk["durations"].cpu().numpy()
+    for b in (0, 13, 31):
+        alone = model.infer_batch([xs[b]])
+        assert np.array_equal(alone["packed"]["durations"].cpu().numpy(), dur[cu_p[b]:cu_p[b + 1]])
+        T = pk["olens"][b]
+        assert alone["olens"][0] == T
+        assert (alone["mel"][0, :T] - out["mel"][b, :T]).abs().max().item() <= BF16_MEL_TOL
 
 
 @pytest.mark.parametrize("precision,tol,flips", [("bf16", BF16_MEL_TOL, 0.02), ("fp32", FP32_MEL_TOL, 0.001)])
