@@ -267,6 +267,323 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
     }
 }
 
+// ---- bf16, 32x32x16 MFMA, softmax of tile t under QK^T of tile t+1 ------------------------------------------
+// Same work split and orientation as above (one wave = 32 queries, S^T = K . Q^T, O^T = V^T . P^T), on
+// v_mfma_f32_32x32x16_bf16: it keeps the SIMD's vector issue for 8 of its 32 cycles (the 16x16x32 form for 8 of 16), so
+// the softmax VALU work fits beside the matrix work.  Lane (hi = lane / 32, lo = lane % 32) owns query lo of the
+// wave's 32 and, of every 32-key block, the 16 keys 8 (r / 4) + 4 hi + r % 4 (r = accumulator register): the row
+// statistics are 31 in-lane operations plus one v_permlane32_swap.  The P fragment is used as held: of the 16-key step
+// j of a block, k-slot (hi, e) is key 16 j + 8 (e / 4) + 4 hi + e % 4, and V^T is read with that map by two
+// ds_read_b64_tr_b16 (4 keys x 16 dv per 16-lane group).
+// Pipeline: K and V rings of two 64-key tiles each.  Iteration t: barrier; DMA of K(t+2) and V(t+1) issued;
+// S(t+1) = K(t+1) . Q^T (independent of the softmax, the scheduler interleaves them); softmax of S(t); O += V(t)^T P(t)^T.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// both halves of the wave hold the same query in lane % 32
+__device__ __forceinline__ float halves_max(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float halves_sum(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);
+    return a + b;
+}
+
+// Transposed LDS read issued from inline asm.  Through the builtin, hipcc (ROCm 7.2) makes every such read that follows
+// an LDS-DMA in program order wait for vmcnt(0) first (it cannot tell that the DMA fills another buffer): the DMA of
+// the next tile would be waited for in the middle of the current one.  The compiler does not track these reads: the
+// consumer waits with lds_tr_wait() (lgkmcnt(0)) and takes the registers through it, which orders the uses behind it.
+template <int OFF> __device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void lds_tr_wait(bf16x4 (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+
+template <int DK, bool DROP, bool PIPE>
+__global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) {
+    typedef bf16_t T;
+    constexpr int ROWB = DK * 2;                     // bytes per K/V row
+    constexpr int NS = ROWB / 16;                    // 16-byte slots per row
+    constexpr int TILE_BYTES = AT_BK * ROWB;
+    constexpr int PIECES = TILE_BYTES / 1024;        // 1-KiB DMA pieces per tile
+    constexpr int KS = DK / 16;                      // k-steps of Q . K over dk
+    constexpr int DB = DK / 32;                      // 32-wide dv blocks
+    constexpr int RSH = ROWB == 256 ? 0 : (ROWB == 128 ? 1 : (ROWB == 64 ? 2 : 0));
+    constexpr bool POW2 = (NS & (NS - 1)) == 0;
+    constexpr int BQ = 128;                          // queries per workgroup
+    static_assert(PIECES % 4 == 0, "one DMA piece per wave and step");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // K ring: smem + {0, 1} * TILE_BYTES; V ring: smem + {2, 3} * TILE_BYTES
+
+    int b, h, qblk;
+    if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
+    const int r0 = a.cu[b];
+    const int len = a.cu[b + 1] - r0;
+    if (qblk * BQ >= len) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, lo = lane & 31;
+    const T* __restrict__ base = (const T*)a.qkv + (size_t)r0 * a.ld;
+    const int qcol = h * DK, kcol = a.d + h * DK, vcol = 2 * a.d + h * DK;
+
+    // Slot swizzles (XOR, a rotation for the 12-slot rows of dk = 96): K rows are read 16 rows x one 16-byte slot at a
+    // time (ds_read_b128 lane groups), V rows 4 rows x 64 bytes at a time (transposed reads, 32 lanes); both then
+    // spread over all 64 banks.  Physical slot p of a row holds logical slot swz(p, row).
+    auto swz_k = [](int slot, int row) {
+        return POW2 ? (slot ^ ((row >> RSH) & (NS - 1))) : (slot + NS - (row % NS)) % NS;
+    };
+    auto swz_v = [](int slot, int row) {
+        return ROWB == 256 ? (slot ^ (4 * (row & 3))) : (ROWB == 128 ? (slot ^ (4 * ((row >> 1) & 1))) : slot);
+    };
+    auto unswz_k = [](int slot, int row) {      // physical slot of logical slot `slot`
+        return POW2 ? (slot ^ ((row >> RSH) & (NS - 1))) : (slot + row) % NS;
+    };
+
+    // One 1-KiB piece per wave and step pp: piece p = wave + 4 pp covers rows (p * 1024 + 16 lane) / ROWB.  The source is
+    // a 32-bit byte offset from the utterance's first row (scalar base + vector offset); everything lane-dependent is
+    // rebuilt from `lane` at every call (the opaque copy keeps the compiler from carrying per-piece addresses through
+    // the tile loop, where they were spilled and their reloads' waits serialised the DMA).
+    const unsigned ldb = (unsigned)a.ld * 2u;
+    auto stage = [&](int kt, unsigned char* dst, int col, bool is_v) __attribute__((always_inline)) {
+        const int k0 = kt * AT_BK;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int pp = 0; pp < PIECES / 4; ++pp) {
+            const int p = wave + 4 * pp;
+            const unsigned off = (unsigned)(p * 1024 + ln * 16);
+            const int row = (int)(off / (unsigned)ROWB);
+            const int slot = (int)(off % (unsigned)ROWB) >> 4;
+            int key = k0 + row;
+            key = key < len ? key : len - 1;       // tail keys are masked (-inf); keep the address valid
+            const int src_slot = is_v ? swz_v(slot, row) : swz_k(slot, row);
+            const unsigned boff = __umul24((unsigned)key, ldb) + (unsigned)((col + src_slot * 8) * 2);
+            __builtin_amdgcn_global_load_lds((at_gbl_void*)((const unsigned char*)base + boff), (at_lds_void*)(dst + p * 1024),
+                                             16, 0, 0);
+        }
+    };
+
+    // Q fragments (B operand): Q[query lo][dk = 16 ks + 8 hi ..]
+    const int qrow = qblk * BQ + wave * 32 + lo;
+    bf16x8 qf[KS];
+    {
+        const int qc = qrow < len ? qrow : len - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qc * a.ld + qcol + ks * 16 + hi * 8);
+    }
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m_run = -INFINITY, l_part = 0.f;
+
+    // K fragment of k-step ks, key lo of a block: byte lo * ROWB + ((2 ks + hi) ^ x) * 16 = kx ^ (32 ks)
+    const int kx0 = lo * ROWB + ((hi ^ ((lo >> RSH) & (NS - 1))) << 4);
+    // V^T fragments: 16-lane group gg = lane / 16 reads a 4-key x 16-dv block; lane 4 q + p of the group supplies
+    // key q, dv 4 p .. 4 p + 3 and receives the 4 keys of dv (lane % 16).  Keys 4 hi + q (+ 8 for the second read) of a
+    // 16-key step, dv block db: byte (4 hi + q) ROWB + (64 db ^ swizzle) + 32 (gg & 1) + 8 p = vx ^ (64 db)
+    const int vq = (lane & 15) >> 2, vp = lane & 3, gg1 = (lane >> 4) & 1;
+    const int vx0 = (4 * hi + vq) * ROWB + gg1 * 32 + vp * 8 +
+                   (ROWB == 256 ? 64 * vq : (ROWB == 128 ? 64 * ((vq >> 1) & 1) : 0));
+
+    // S^T of one tile: s[kb][r] = score(key 32 kb + 8 (r / 4) + 4 hi + r % 4, query lo)
+    auto qk = [&](const unsigned char* Ks, f32x16 (&s)[2]) __attribute__((always_inline)) {
+        int kx = kx0;
+        asm volatile("" : "+v"(kx));      // the per-step addresses are rebuilt per tile, not carried through the loop
+        // all K fragments of the tile are requested before the first MFMA (each MFMA then waits for its own fragment
+        // only: LDS returns in order); left to itself the compiler keeps two reads in flight and exposes the LDS latency
+        // once per MFMA pair
+        bf16x8 kf[2][KS];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // row 32 kb + lo; a power-of-two swizzle depends on lo alone (32 kb is a multiple of its period)
+                const int koff = POW2 ? (kx ^ (ks * 32)) : (lo * ROWB + unswz_k(ks * 2 + hi, kb * 32 + lo) * 16);
+                kf[kb][ks] = *(const bf16x8*)(Ks + kb * 32 * ROWB + koff);
+            }
+        if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
+        }
+    };
+
+    // softmax of tile kt (scores in s) and O^T += V^T . P^T
+    auto softmax_pv = [&](int kt, const unsigned char* Vs, f32x16 (&s)[2]) __attribute__((always_inline)) {
+        const int k0 = kt * AT_BK;
+        // V^T fragments are requested first: they land under the softmax arithmetic
+        bf16x4 vf[DB][8];      // [db][4 kb + 2 j + half]
+        if constexpr (!PIPE) {
+            int vx = vx0;
+            asm volatile("" : "+v"(vx));
+            const unsigned vs = (unsigned)(size_t)(at_lds_void*)Vs;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const unsigned vb = vs + (unsigned)(POW2 ? (vx ^ (db * 64)) : (vx + db * 64));   // dk = 96: unswizzled
+                vf[db][0] = lds_read_tr<0 * ROWB>(vb);
+                vf[db][1] = lds_read_tr<8 * ROWB>(vb);
+                vf[db][2] = lds_read_tr<16 * ROWB>(vb);
+                vf[db][3] = lds_read_tr<24 * ROWB>(vb);
+                vf[db][4] = lds_read_tr<32 * ROWB>(vb);
+                vf[db][5] = lds_read_tr<40 * ROWB>(vb);
+                vf[db][6] = lds_read_tr<48 * ROWB>(vb);
+                vf[db][7] = lds_read_tr<56 * ROWB>(vb);
+            }
+        }
+        if ((k0 + AT_BK) > len) {     // last tile only: keys beyond the utterance get -inf (exp2 -> exactly 0)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((k0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) >= len) s[kb][r] = -INFINITY;
+        }
+        float m_loc = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m_loc = fmaxf(m_loc, s[kb][r]);
+        m_loc = halves_max(m_loc) * a.scale_log2e;                  // scale > 0: the maximum commutes with it
+        const float m_new = fmaxf(m_run, m_loc);                    // finite: every tile has >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // v_exp_f32: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], a.scale_log2e, -m_new));
+                s[kb][r] = p;
+                psum += p;
+            }
+        l_part = l_part * alpha + psum;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        if constexpr (DROP) {     // the row sum above used the undropped p: softmax first, dropout after
+            Dropout dh = a.drop;
+            dh.stream += (uint32_t)h;
+            const uint32_t qg = (uint32_t)(r0 + qrow);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s[kb][r] *= drop_mul(dh, qg, (uint32_t)(k0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)));
+        }
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[kb][j][e] = (bf16_t)s[kb][8 * j + e];
+        int vx = vx0;
+        if constexpr (PIPE) asm volatile("" : "+v"(vx));
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            if constexpr (PIPE) {
+                const unsigned char* vb = Vs + (POW2 ? (vx ^ (db * 64)) : (vx + db * 64));
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    vf[db][e] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vb + e * 8 * ROWB));
+            } else {
+                lds_tr_wait(vf[db]);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bf16x8 v8;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v8[r] = vf[db][4 * kb + 2 * j][r];
+                        v8[4 + r] = vf[db][4 * kb + 2 * j + 1][r];
+                    }
+                    o[db] = mma32(v8, pf[kb][j], o[db]);
+                }
+        }
+    };
+
+    const int ntiles = (len + AT_BK - 1) / AT_BK;
+    unsigned char* const Kr = smem;
+    unsigned char* const Vr = smem + 2 * TILE_BYTES;
+    if constexpr (PIPE) {
+        stage(0, Kr, kcol, false);
+        stage(0, Vr, vcol, true);
+        if (ntiles > 1) stage(1, Kr + TILE_BYTES, kcol, false);
+        __syncthreads();
+        f32x16 sa[2], sb[2];
+        qk(Kr, sa);
+        // two tiles per trip so that the two score sets keep their names (no register copies, no dynamic indexing)
+        for (int kt = 0; kt < ntiles; kt += 2) {
+            __syncthreads();   // K(kt+1), V(kt) landed; every wave is done with K(kt) and V(kt-1)
+            if (kt + 2 < ntiles) stage(kt + 2, Kr, kcol, false);
+            if (kt + 1 < ntiles) {
+                stage(kt + 1, Vr + TILE_BYTES, vcol, true);
+                qk(Kr + TILE_BYTES, sb);
+            }
+            softmax_pv(kt, Vr, sa);
+            if (kt + 1 >= ntiles) break;
+            __syncthreads();   // K(kt+2), V(kt+1) landed; every wave is done with K(kt+1) and V(kt)
+            if (kt + 3 < ntiles) stage(kt + 3, Kr + TILE_BYTES, kcol, false);
+            if (kt + 2 < ntiles) {
+                stage(kt + 2, Vr, vcol, true);
+                qk(Kr, sa);
+            }
+            softmax_pv(kt + 1, Vr + TILE_BYTES, sb);
+        }
+    } else {
+        stage(0, Kr, kcol, false);
+        stage(0, Vr, vcol, true);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            __syncthreads();   // tile kt landed; every wave is done with tile kt - 1
+            const int st = kt & 1;
+            if (kt + 1 < ntiles) {
+                stage(kt + 1, Kr + (st ^ 1) * TILE_BYTES, kcol, false);
+                stage(kt + 1, Vr + (st ^ 1) * TILE_BYTES, vcol, true);
+            }
+            f32x16 sc[2];
+            qk(Kr + st * TILE_BYTES, sc);
+            softmax_pv(kt, Vr + st * TILE_BYTES, sc);
+        }
+    }
+
+    float l = halves_sum(l_part);
+    const float inv = 1.0f / l;
+    if (qrow < len) {
+        if (a.lse && hi == 0) a.lse[(size_t)h * a.M + r0 + qrow] = m_run + __log2f(l);
+        T* dst = (T*)a.ctx + (size_t)(r0 + qrow) * a.ldo + h * DK;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = o[db][4 * rr + r] * inv;
+                store4<T>(dst + db * 32 + 8 * rr + 4 * hi, v);
+            }
+    }
+}
+
 // Debug path for calculate_all_attentions (network/fastspeech2.py:305-341): materialises the
 // softmax matrix of one utterance, atten[h][T][T] fp32.  One wave per (head, query) row.
 template <typename T>
@@ -307,6 +624,24 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
     static const int xcd_on = getenv("FS2_ATTN_XCD") ? atoi(getenv("FS2_ATTN_XCD")) : 1;   // 0: plain grid (A/B runs)
     AttnArgs aa = a;
     const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 64 * QT - 1) / (64 * QT), H, B, xcd_on != 0);
+    if constexpr (sizeof(T) == 2) {
+        static const int v1 = getenv("FS2_ATTN_V1") ? atoi(getenv("FS2_ATTN_V1")) : 0;   // 1: the 16x16x32 kernel (A/B runs)
+        if (!v1) {
+            static unsigned long long lds32_ok = 0, lds32d_ok = 0, lds32p_ok = 0;
+            static const int pipe = getenv("FS2_ATTN_PIPE") ? atoi(getenv("FS2_ATTN_PIPE")) : 0;
+            fs2_allow_lds((const void*)attention32_kernel<DK, false, false>, lds, &lds32_ok);
+            fs2_allow_lds((const void*)attention32_kernel<DK, true, false>, lds, &lds32d_ok);
+            fs2_allow_lds((const void*)attention32_kernel<DK, false, true>, lds, &lds32p_ok);
+            if (aa.drop.thresh)
+                hipLaunchKernelGGL((attention32_kernel<DK, true, false>), grid, dim3(AT_THREADS), lds, stream, aa);
+            else if (pipe)
+                hipLaunchKernelGGL((attention32_kernel<DK, false, true>), grid, dim3(AT_THREADS), lds, stream, aa);
+            else
+                hipLaunchKernelGGL((attention32_kernel<DK, false, false>), grid, dim3(AT_THREADS), lds, stream, aa);
+            FS2_CHECK_LAUNCH("fs2_attention");
+            return FS2_OK;
+        }
+    }
     hipLaunchKernelGGL((attention_kernel<T, DK, QT>), grid, dim3(AT_THREADS), lds, stream, aa);
     FS2_CHECK_LAUNCH("fs2_attention");
     return FS2_OK;
