@@ -267,16 +267,24 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
     }
 }
 
-// ---- bf16, 32x32x16 MFMA, softmax of tile t under QK^T of tile t+1 ------------------------------------------
-// Same work split and orientation as above (one wave = 32 queries, S^T = K . Q^T, O^T = V^T . P^T), on
-// v_mfma_f32_32x32x16_bf16: it keeps the SIMD's vector issue for 8 of its 32 cycles (the 16x16x32 form for 8 of 16), so
-// the softmax VALU work fits beside the matrix work.  Lane (hi = lane / 32, lo = lane % 32) owns query lo of the
-// wave's 32 and, of every 32-key block, the 16 keys 8 (r / 4) + 4 hi + r % 4 (r = accumulator register): the row
-// statistics are 31 in-lane operations plus one v_permlane32_swap.  The P fragment is used as held: of the 16-key step
-// j of a block, k-slot (hi, e) is key 16 j + 8 (e / 4) + 4 hi + e % 4, and V^T is read with that map by two
-// ds_read_b64_tr_b16 (4 keys x 16 dv per 16-lane group).
-// Pipeline: K and V rings of two 64-key tiles each.  Iteration t: barrier; DMA of K(t+2) and V(t+1) issued;
-// S(t+1) = K(t+1) . Q^T (independent of the softmax, the scheduler interleaves them); softmax of S(t); O += V(t)^T P(t)^T.
+// ---- bf16: 32x32x16 MFMA, one or two key groups per workgroup --------------------------------------------------
+// Same orientation as above (one wave = 32 queries, S^T = K . Q^T, O^T = V^T . P^T), on v_mfma_f32_32x32x16_bf16: it
+// keeps the SIMD's vector issue for 8 of its 32 cycles (the 16x16x32 form for 8 of 16), which leaves room for the
+// softmax arithmetic.  Lane (hi = lane / 32, lo = lane % 32) owns query lo of the wave's 32 and, of every 32-key
+// block, the 16 keys 8 (r / 4) + 4 hi + r % 4 (r = accumulator register): the row statistics are in-lane operations
+// plus one v_permlane32_swap.  The P fragment is used as held: of the 16-key step j of a block, k-slot (hi, e) is key
+// 16 j + 8 (e / 4) + 4 hi + e % 4, and V^T is read with that map by two ds_read_b64_tr_b16 (4 keys x 16 dv per 16-lane
+// group).
+// Per tile: barrier, DMA of the next tile issued, all 16 K fragments requested, 16 MFMAs, all 32 V^T fragments
+// requested (they land under the softmax arithmetic), softmax, 16 MFMAs.
+// G = 2 (512 threads, one workgroup per CU): waves 4..7 take the second half of the utterance's key tiles for the same
+// 128 queries, with their own K/V ring; the two partial results (O, m, l) are merged through LDS at the end.  The
+// workgroups of a launch then last half as long and there are more of them than CUs, so that utterances of different
+// length balance over the chip (with G = 1 every workgroup is resident from the start and the longest utterance sets
+// the time), and a single long utterance fills twice the SIMDs.
+#ifndef FS2_ATT_ABL
+#define FS2_ATT_ABL 0      // timing ablations (tools/build_variant.sh): 1 no exp, 2 one PV MFMA in four, 3 one QK MFMA in eight
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
@@ -308,8 +316,8 @@ __device__ __forceinline__ void lds_tr_wait(bf16x4 (&v)[8]) {
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
 
-template <int DK, bool DROP, bool PIPE>
-__global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) {
+template <int DK, bool DROP, int G>
+__global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(AttnArgs a) {
     typedef bf16_t T;
     constexpr int ROWB = DK * 2;                     // bytes per K/V row
     constexpr int NS = ROWB / 16;                    // 16-byte slots per row
@@ -321,9 +329,10 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
     constexpr bool POW2 = (NS & (NS - 1)) == 0;
     constexpr int BQ = 128;                          // queries per workgroup
     static_assert(PIECES % 4 == 0, "one DMA piece per wave and step");
+    static_assert(G == 1 || 8 * TILE_BYTES >= 4 * 64 * (16 * DB + 2) * 4, "the merge buffer reuses the K/V rings");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // K ring: smem + {0, 1} * TILE_BYTES; V ring: smem + {2, 3} * TILE_BYTES
+    // per key group: K ring at {0, 1} * TILE_BYTES, V ring at {2, 3} * TILE_BYTES of its 4 * TILE_BYTES
 
     int b, h, qblk;
     if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
@@ -332,10 +341,17 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
     if (qblk * BQ >= len) return;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, grp = wave8 >> 2;    // wave within its key group, key group
     const int hi = lane >> 5, lo = lane & 31;
     const T* __restrict__ base = (const T*)a.qkv + (size_t)r0 * a.ld;
     const int qcol = h * DK, kcol = a.d + h * DK, vcol = 2 * a.d + h * DK;
+
+    // key tiles [t0, t1) of this group; every group runs `trips` iterations (barriers are workgroup-wide)
+    const int ntiles = (len + AT_BK - 1) / AT_BK;
+    const int trips = (ntiles + G - 1) / G;
+    const int t0 = grp * trips;
+    const int t1 = (t0 + trips) < ntiles ? (t0 + trips) : ntiles;
 
     // Slot swizzles (XOR, a rotation for the 12-slot rows of dk = 96): K rows are read 16 rows x one 16-byte slot at a
     // time (ds_read_b128 lane groups), V rows 4 rows x 64 bytes at a time (transposed reads, 32 lanes); both then
@@ -350,27 +366,35 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
         return POW2 ? (slot ^ ((row >> RSH) & (NS - 1))) : (slot + row) % NS;
     };
 
-    // One 1-KiB piece per wave and step pp: piece p = wave + 4 pp covers rows (p * 1024 + 16 lane) / ROWB.  The source is
-    // a 32-bit byte offset from the utterance's first row (scalar base + vector offset); everything lane-dependent is
-    // rebuilt from `lane` at every call (the opaque copy keeps the compiler from carrying per-piece addresses through
-    // the tile loop, where they were spilled and their reloads' waits serialised the DMA).
+    // DMA: one 1-KiB piece per wave and step pp: piece p = wave + 4 pp covers rows (p * 1024 + 16 lane) / ROWB.  The
+    // source is a 32-bit byte offset from the utterance's first row (scalar base + vector offset), carried from tile to
+    // tile: src[v][pp] (v = 0: K, 1: V) advances by 64 rows per call; rows beyond the utterance (last tile only; masked
+    // with -inf later) read its last row instead: min() with the same piece's offset in that row.
+    constexpr int PP = PIECES / 4;
+    constexpr int LC = POW2 ? 1 : PP;               // power-of-two rows: the in-row part is the same for every pp
     const unsigned ldb = (unsigned)a.ld * 2u;
-    auto stage = [&](int kt, unsigned char* dst, int col, bool is_v) __attribute__((always_inline)) {
-        const int k0 = kt * AT_BK;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+    const unsigned tile_step = AT_BK * ldb;
+    unsigned src[2][PP], src_last[2][LC];
 #pragma unroll
-        for (int pp = 0; pp < PIECES / 4; ++pp) {
-            const int p = wave + 4 * pp;
-            const unsigned off = (unsigned)(p * 1024 + ln * 16);
-            const int row = (int)(off / (unsigned)ROWB);
-            const int slot = (int)(off % (unsigned)ROWB) >> 4;
-            int key = k0 + row;
-            key = key < len ? key : len - 1;       // tail keys are masked (-inf); keep the address valid
-            const int src_slot = is_v ? swz_v(slot, row) : swz_k(slot, row);
-            const unsigned boff = __umul24((unsigned)key, ldb) + (unsigned)((col + src_slot * 8) * 2);
-            __builtin_amdgcn_global_load_lds((at_gbl_void*)((const unsigned char*)base + boff), (at_lds_void*)(dst + p * 1024),
-                                             16, 0, 0);
+    for (int pp = 0; pp < PP; ++pp) {
+        const unsigned off = (unsigned)((wave + 4 * pp) * 1024 + lane * 16);
+        const int row = (int)(off / (unsigned)ROWB);
+        const int slot = (int)(off % (unsigned)ROWB) >> 4;
+        const unsigned ck = (unsigned)((kcol + swz_k(slot, row) * 8) * 2), cv = (unsigned)((vcol + swz_v(slot, row) * 8) * 2);
+        src[0][pp] = (unsigned)(t0 * AT_BK + row) * ldb + ck;
+        src[1][pp] = (unsigned)(t0 * AT_BK + row) * ldb + cv;
+        if (pp < LC) {
+            src_last[0][pp] = (unsigned)(len - 1) * ldb + ck;
+            src_last[1][pp] = (unsigned)(len - 1) * ldb + cv;
+        }
+    }
+    auto stage = [&](int v, unsigned char* dst) __attribute__((always_inline)) {      // next tile of stream v
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const unsigned so = src[v][pp] < src_last[v][POW2 ? 0 : pp] ? src[v][pp] : src_last[v][POW2 ? 0 : pp];
+            __builtin_amdgcn_global_load_lds((at_gbl_void*)((const unsigned char*)base + so),
+                                             (at_lds_void*)(dst + (wave + 4 * pp) * 1024), 16, 0, 0);
+            src[v][pp] += tile_step;
         }
     };
 
@@ -397,40 +421,47 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
     // 16-key step, dv block db: byte (4 hi + q) ROWB + (64 db ^ swizzle) + 32 (gg & 1) + 8 p = vx ^ (64 db)
     const int vq = (lane & 15) >> 2, vp = lane & 3, gg1 = (lane >> 4) & 1;
     const int vx0 = (4 * hi + vq) * ROWB + gg1 * 32 + vp * 8 +
-                   (ROWB == 256 ? 64 * vq : (ROWB == 128 ? 64 * ((vq >> 1) & 1) : 0));
+                    (ROWB == 256 ? 64 * vq : (ROWB == 128 ? 64 * ((vq >> 1) & 1) : 0));
 
-    // S^T of one tile: s[kb][r] = score(key 32 kb + 8 (r / 4) + 4 hi + r % 4, query lo)
-    auto qk = [&](const unsigned char* Ks, f32x16 (&s)[2]) __attribute__((always_inline)) {
-        int kx = kx0;
-        asm volatile("" : "+v"(kx));      // the per-step addresses are rebuilt per tile, not carried through the loop
-        // all K fragments of the tile are requested before the first MFMA (each MFMA then waits for its own fragment
-        // only: LDS returns in order); left to itself the compiler keeps two reads in flight and exposes the LDS latency
-        // once per MFMA pair
-        bf16x8 kf[2][KS];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                // row 32 kb + lo; a power-of-two swizzle depends on lo alone (32 kb is a multiple of its period)
-                const int koff = POW2 ? (kx ^ (ks * 32)) : (lo * ROWB + unswz_k(ks * 2 + hi, kb * 32 + lo) * 16);
-                kf[kb][ks] = *(const bf16x8*)(Ks + kb * 32 * ROWB + koff);
-            }
-        if constexpr (!PIPE) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
-        }
-    };
-
-    // softmax of tile kt (scores in s) and O^T += V^T . P^T
-    auto softmax_pv = [&](int kt, const unsigned char* Vs, f32x16 (&s)[2]) __attribute__((always_inline)) {
+    // one key tile: s = K . Q^T; online softmax; O^T += V^T . P^T
+    auto tile = [&](int kt, const unsigned char* Ks, const unsigned char* Vs) __attribute__((always_inline)) {
         const int k0 = kt * AT_BK;
-        // V^T fragments are requested first: they land under the softmax arithmetic
+        f32x16 s[2];      // s[kb][r] = score(key 32 kb + 8 (r / 4) + 4 hi + r % 4, query lo)
+        {
+            int kx = kx0;
+            asm volatile("" : "+v"(kx));      // the per-step addresses are rebuilt per tile, not carried through the loop
+            // all K fragments of the tile are requested before the first MFMA; left to itself the compiler keeps two
+            // reads in flight and exposes the LDS latency once per MFMA pair
+            bf16x8 kf[2][KS];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    // row 32 kb + lo; a power-of-two swizzle depends on lo alone (32 kb is a multiple of its period)
+                    const int koff = POW2 ? (kx ^ (ks * 32)) : (lo * ROWB + unswz_k(ks * 2 + hi, kb * 32 + lo) * 16);
+                    kf[kb][ks] = *(const bf16x8*)(Ks + kb * 32 * ROWB + koff);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#if FS2_ATT_ABL == 3
+                    if (ks == 0) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[kb][r] += (float)kf[kb][ks][r] * (float)qf[ks][r];
+#else
+                    s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
+#endif
+                }
+            }
+        }
+        // V^T fragments are requested now: they land under the softmax arithmetic
         bf16x4 vf[DB][8];      // [db][4 kb + 2 j + half]
-        if constexpr (!PIPE) {
+        {
             int vx = vx0;
             asm volatile("" : "+v"(vx));
             const unsigned vs = (unsigned)(size_t)(at_lds_void*)Vs;
@@ -468,7 +499,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if FS2_ATT_ABL == 1
+                const float p = __builtin_fmaf(s[kb][r], a.scale_log2e, -m_new);
+#else
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], a.scale_log2e, -m_new));
+#endif
                 s[kb][r] = p;
                 psum += p;
             }
@@ -496,18 +531,9 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[kb][j][e] = (bf16_t)s[kb][8 * j + e];
-        int vx = vx0;
-        if constexpr (PIPE) asm volatile("" : "+v"(vx));
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            if constexpr (PIPE) {
-                const unsigned char* vb = Vs + (POW2 ? (vx ^ (db * 64)) : (vx + db * 64));
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    vf[db][e] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(vb + e * 8 * ROWB));
-            } else {
-                lds_tr_wait(vf[db]);
-            }
+            lds_tr_wait(vf[db]);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -518,56 +544,61 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention32_kernel(AttnArgs a) 
                         v8[r] = vf[db][4 * kb + 2 * j][r];
                         v8[4 + r] = vf[db][4 * kb + 2 * j + 1][r];
                     }
+#if FS2_ATT_ABL == 2
+                    if (kb + j == 0) o[db] = mma32(v8, pf[kb][j], o[db]);
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[db][r] += (float)v8[r] * (float)pf[kb][j][r];
+#else
                     o[db] = mma32(v8, pf[kb][j], o[db]);
+#endif
                 }
         }
     };
 
-    const int ntiles = (len + AT_BK - 1) / AT_BK;
-    unsigned char* const Kr = smem;
-    unsigned char* const Vr = smem + 2 * TILE_BYTES;
-    if constexpr (PIPE) {
-        stage(0, Kr, kcol, false);
-        stage(0, Vr, vcol, true);
-        if (ntiles > 1) stage(1, Kr + TILE_BYTES, kcol, false);
-        __syncthreads();
-        f32x16 sa[2], sb[2];
-        qk(Kr, sa);
-        // two tiles per trip so that the two score sets keep their names (no register copies, no dynamic indexing)
-        for (int kt = 0; kt < ntiles; kt += 2) {
-            __syncthreads();   // K(kt+1), V(kt) landed; every wave is done with K(kt) and V(kt-1)
-            if (kt + 2 < ntiles) stage(kt + 2, Kr, kcol, false);
-            if (kt + 1 < ntiles) {
-                stage(kt + 1, Vr + TILE_BYTES, vcol, true);
-                qk(Kr + TILE_BYTES, sb);
-            }
-            softmax_pv(kt, Vr, sa);
-            if (kt + 1 >= ntiles) break;
-            __syncthreads();   // K(kt+2), V(kt+1) landed; every wave is done with K(kt+1) and V(kt)
-            if (kt + 3 < ntiles) stage(kt + 3, Kr + TILE_BYTES, kcol, false);
-            if (kt + 2 < ntiles) {
-                stage(kt + 2, Vr, vcol, true);
-                qk(Kr, sa);
-            }
-            softmax_pv(kt + 1, Vr + TILE_BYTES, sb);
+    unsigned char* const Kr = smem + grp * 4 * TILE_BYTES;
+    unsigned char* const Vr = Kr + 2 * TILE_BYTES;
+    if (t0 < t1) {
+        stage(0, Kr);
+        stage(1, Vr);
+    }
+    for (int it = 0; it < trips; ++it) {
+        __syncthreads();   // this trip's tile landed; every wave is done with the previous one
+        const int kt = t0 + it;
+        const int st = it & 1;
+        if (kt + 1 < t1) {
+            stage(0, Kr + (st ^ 1) * TILE_BYTES);
+            stage(1, Vr + (st ^ 1) * TILE_BYTES);
         }
-    } else {
-        stage(0, Kr, kcol, false);
-        stage(0, Vr, vcol, true);
-        for (int kt = 0; kt < ntiles; ++kt) {
-            __syncthreads();   // tile kt landed; every wave is done with tile kt - 1
-            const int st = kt & 1;
-            if (kt + 1 < ntiles) {
-                stage(kt + 1, Kr + (st ^ 1) * TILE_BYTES, kcol, false);
-                stage(kt + 1, Vr + (st ^ 1) * TILE_BYTES, vcol, true);
-            }
-            f32x16 sc[2];
-            qk(Kr + st * TILE_BYTES, sc);
-            softmax_pv(kt, Vr + st * TILE_BYTES, sc);
-        }
+        if (kt < t1) tile(kt, Kr + st * TILE_BYTES, Vr + st * TILE_BYTES);
     }
 
     float l = halves_sum(l_part);
+    if constexpr (G == 2) {
+        // merge of the two key groups: group 1 leaves (O, m, l) in LDS in its own register / lane order, the wave of
+        // group 0 with the same queries (same wave index, same lanes) folds them in
+        __syncthreads();
+        float* mb = (float*)smem + wave * (16 * DB + 2) * 64 + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mb[(db * 16 + r) * 64] = o[db][r];
+            mb[(16 * DB) * 64] = m_run;
+            mb[(16 * DB + 1) * 64] = l;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m_b = mb[(16 * DB) * 64], l_b = mb[(16 * DB + 1) * 64];
+        const float m_new = fmaxf(m_run, m_b);                       // group 0 always has a tile: finite
+        const float fa = __builtin_amdgcn_exp2f(m_run - m_new), fb = __builtin_amdgcn_exp2f(m_b - m_new);
+        m_run = m_new;
+        l = l * fa + l_b * fb;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = o[db][r] * fa + mb[(db * 16 + r) * 64] * fb;
+    }
     const float inv = 1.0f / l;
     if (qrow < len) {
         if (a.lse && hi == 0) a.lse[(size_t)h * a.M + r0 + qrow] = m_run + __log2f(l);
@@ -626,19 +657,23 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
     const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 64 * QT - 1) / (64 * QT), H, B, xcd_on != 0);
     if constexpr (sizeof(T) == 2) {
         static const int v1 = getenv("FS2_ATTN_V1") ? atoi(getenv("FS2_ATTN_V1")) : 0;   // 1: the 16x16x32 kernel (A/B runs)
+        static const int groups = getenv("FS2_ATTN_GROUPS") ? atoi(getenv("FS2_ATTN_GROUPS")) : 0;   // 1 / 2: forced
         if (!v1) {
-            static unsigned long long lds32_ok = 0, lds32d_ok = 0, lds32p_ok = 0;
-            static const int pipe = getenv("FS2_ATTN_PIPE") ? atoi(getenv("FS2_ATTN_PIPE")) : 0;
-            fs2_allow_lds((const void*)attention32_kernel<DK, false, false>, lds, &lds32_ok);
-            fs2_allow_lds((const void*)attention32_kernel<DK, true, false>, lds, &lds32d_ok);
-            fs2_allow_lds((const void*)attention32_kernel<DK, false, true>, lds, &lds32p_ok);
-            if (aa.drop.thresh)
-                hipLaunchKernelGGL((attention32_kernel<DK, true, false>), grid, dim3(AT_THREADS), lds, stream, aa);
-            else if (pipe)
-                hipLaunchKernelGGL((attention32_kernel<DK, false, true>), grid, dim3(AT_THREADS), lds, stream, aa);
-            else
-                hipLaunchKernelGGL((attention32_kernel<DK, false, false>), grid, dim3(AT_THREADS), lds, stream, aa);
-            FS2_CHECK_LAUNCH("fs2_attention");
+            // two key groups per workgroup when one-group workgroups would leave CUs empty (measured: 66 workgroups,
+            // config 4 B = 1, 86 -> 71 us; 264 or 448 workgroups are 10 % faster with one group, two per CU)
+            const long items = (long)B * H * ((max_len + 127) / 128);
+            const bool two = groups ? groups == 2 : (max_len > 4 * AT_BK && items <= 256);
+            static unsigned long long ok[4] = {0, 0, 0, 0};
+            const void* k;
+            if (two) k = aa.drop.thresh ? (const void*)attention32_kernel<DK, true, 2> : (const void*)attention32_kernel<DK, false, 2>;
+            else k = aa.drop.thresh ? (const void*)attention32_kernel<DK, true, 1> : (const void*)attention32_kernel<DK, false, 1>;
+            const int lds32 = (two ? 2 : 1) * lds;
+            fs2_allow_lds(k, lds32, &ok[(two ? 2 : 0) + (aa.drop.thresh ? 1 : 0)]);
+            void* params[] = {&aa};
+            if (hipLaunchKernel(k, grid, dim3(AT_THREADS * (two ? 2 : 1)), params, lds32, stream) != hipSuccess) {
+                fs2_set_error("fs2_attention: launch failed: %s", hipGetErrorString(hipGetLastError()));
+                return FS2_ERR_HIP;
+            }
             return FS2_OK;
         }
     }
