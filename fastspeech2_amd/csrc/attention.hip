@@ -282,9 +282,6 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
 // workgroups of a launch then last half as long and there are more of them than CUs, so that utterances of different
 // length balance over the chip (with G = 1 every workgroup is resident from the start and the longest utterance sets
 // the time), and a single long utterance fills twice the SIMDs.
-#ifndef FS2_ATT_ABL
-#define FS2_ATT_ABL 0      // timing ablations (tools/build_variant.sh): 1 no exp, 2 one PV MFMA in four, 3 one QK MFMA in eight
-#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
@@ -371,31 +368,33 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
     // tile: src[v][pp] (v = 0: K, 1: V) advances by 64 rows per call; rows beyond the utterance (last tile only; masked
     // with -inf later) read its last row instead: min() with the same piece's offset in that row.
     constexpr int PP = PIECES / 4;
-    constexpr int LC = POW2 ? 1 : PP;               // power-of-two rows: the in-row part is the same for every pp
+    constexpr int LC = POW2 ? 1 : PP;               // power-of-two rows: piece pp is piece 0 moved down 4096 / ROWB rows
     const unsigned ldb = (unsigned)a.ld * 2u;
     const unsigned tile_step = AT_BK * ldb;
-    unsigned src[2][PP], src_last[2][LC];
+    const unsigned piece_step = (4096 / ROWB) * ldb;
+    unsigned src[2][LC], src_last[2][LC];
 #pragma unroll
-    for (int pp = 0; pp < PP; ++pp) {
+    for (int pp = 0; pp < LC; ++pp) {
         const unsigned off = (unsigned)((wave + 4 * pp) * 1024 + lane * 16);
         const int row = (int)(off / (unsigned)ROWB);
         const int slot = (int)(off % (unsigned)ROWB) >> 4;
         const unsigned ck = (unsigned)((kcol + swz_k(slot, row) * 8) * 2), cv = (unsigned)((vcol + swz_v(slot, row) * 8) * 2);
         src[0][pp] = (unsigned)(t0 * AT_BK + row) * ldb + ck;
         src[1][pp] = (unsigned)(t0 * AT_BK + row) * ldb + cv;
-        if (pp < LC) {
-            src_last[0][pp] = (unsigned)(len - 1) * ldb + ck;
-            src_last[1][pp] = (unsigned)(len - 1) * ldb + cv;
-        }
+        src_last[0][pp] = (unsigned)(len - 1) * ldb + ck;
+        src_last[1][pp] = (unsigned)(len - 1) * ldb + cv;
     }
     auto stage = [&](int v, unsigned char* dst) __attribute__((always_inline)) {      // next tile of stream v
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
-            const unsigned so = src[v][pp] < src_last[v][POW2 ? 0 : pp] ? src[v][pp] : src_last[v][POW2 ? 0 : pp];
+            const unsigned cur = POW2 ? src[v][0] + pp * piece_step : src[v][POW2 ? 0 : pp];
+            const unsigned last = src_last[v][POW2 ? 0 : pp];
+            const unsigned so = cur < last ? cur : last;
             __builtin_amdgcn_global_load_lds((at_gbl_void*)((const unsigned char*)base + so),
                                              (at_lds_void*)(dst + (wave + 4 * pp) * 1024), 16, 0, 0);
-            src[v][pp] += tile_step;
         }
+#pragma unroll
+        for (int pp = 0; pp < LC; ++pp) src[v][pp] += tile_step;
     };
 
     // Q fragments (B operand): Q[query lo][dk = 16 ks + 8 hi ..]
@@ -447,16 +446,7 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-#if FS2_ATT_ABL == 3
-                    if (ks == 0) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
-                    else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s[kb][r] += (float)kf[kb][ks][r] * (float)qf[ks][r];
-#else
-                    s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
-#endif
-                }
+                for (int ks = 0; ks < KS; ++ks) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
             }
         }
         // V^T fragments are requested now: they land under the softmax arithmetic
@@ -499,11 +489,7 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-#if FS2_ATT_ABL == 1
-                const float p = __builtin_fmaf(s[kb][r], a.scale_log2e, -m_new);
-#else
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], a.scale_log2e, -m_new));
-#endif
                 s[kb][r] = p;
                 psum += p;
             }
@@ -544,14 +530,7 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
                         v8[r] = vf[db][4 * kb + 2 * j][r];
                         v8[4 + r] = vf[db][4 * kb + 2 * j + 1][r];
                     }
-#if FS2_ATT_ABL == 2
-                    if (kb + j == 0) o[db] = mma32(v8, pf[kb][j], o[db]);
-                    else
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[db][r] += (float)v8[r] * (float)pf[kb][j][r];
-#else
                     o[db] = mma32(v8, pf[kb][j], o[db]);
-#endif
                 }
         }
     };
@@ -665,8 +644,10 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
             const bool two = groups ? groups == 2 : (max_len > 4 * AT_BK && items <= 256);
             static unsigned long long ok[4] = {0, 0, 0, 0};
             const void* k;
-            if (two) k = aa.drop.thresh ? (const void*)attention32_kernel<DK, true, 2> : (const void*)attention32_kernel<DK, false, 2>;
-            else k = aa.drop.thresh ? (const void*)attention32_kernel<DK, true, 1> : (const void*)attention32_kernel<DK, false, 1>;
+            if (aa.drop.thresh)
+                k = two ? (const void*)attention32_kernel<DK, true, 2> : (const void*)attention32_kernel<DK, true, 1>;
+            else
+                k = two ? (const void*)attention32_kernel<DK, false, 2> : (const void*)attention32_kernel<DK, false, 1>;
             const int lds32 = (two ? 2 : 1) * lds;
             fs2_allow_lds(k, lds32, &ok[(two ? 2 : 0) + (aa.drop.thresh ? 1 : 0)]);
             void* params[] = {&aa};
