@@ -66,6 +66,10 @@ _SIGNATURES = {
     "fs2_pack_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _I, _P],
     "fs2_pack_weights": [_P, _P, _I, _I, _I, _P],
     "fs2_layernorm_rowdot": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    # training-mode BatchNorm of the PostNet
+    "fs2_bn_stats": [_P, _P, _P, _I, _I, _F, _P],
+    "fs2_bn_apply": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _U, _U, _F, _P],
+    "fs2_bn_bwd": [_P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _U, _U, _F, _P],
 }
 # workspace-size queries (return bytes as long long, no launch)
 _SIZE_QUERIES = {
@@ -73,6 +77,7 @@ _SIZE_QUERIES = {
     "fs2_layernorm_bwd_workspace": [_I, _I],
     "fs2_colreduce_workspace": [_I, _I, _I],
     "fs2_colreduce_static_max_bytes": [],
+    "fs2_bn_workspace": [_I, _I],
 }
 # plain int queries (no launch, cannot fail)
 _INT_QUERIES = {

@@ -122,6 +122,8 @@ class _TrainStep(torch.autograd.Function):
         with span("fs2.train_forward"):
             outs, saved = eng.forward(ids, il, ol, ds_p, ps_p, es_p, ys_p)
         l1_loss = F.l1_loss(outs["before"], ys_p)                              # network/fastspeech2.py:271-274
+        if "after" in outs:
+            l1_loss = F.l1_loss(outs["after"], ys_p) + l1_loss
         duration_loss = model.duration_criterion(outs["log_durations"], ds_p)  # network/loss.py:5-14
         pitch_loss = model.mse_criterion(outs["pitch"], ps_p)
         energy_loss = model.mse_criterion(outs["energy"], es_p)
@@ -212,7 +214,8 @@ class FeedForwardTransformer(nn.Module):
                                   enc_att=transformer_enc_atten_dropout_rate, dec=transformer_dec_dropout_rate,
                                   dec_pos=transformer_dec_positional_dropout_rate,
                                   dec_att=transformer_dec_atten_dropout_rate, dur=duration_predictor_dropout_rate,
-                                  var=0.5, pitch_embed=pitch_embed_dropout, energy_embed=energy_embed_dropout)
+                                  var=0.5, pitch_embed=pitch_embed_dropout, energy_embed=energy_embed_dropout,
+                                  postnet=postnet_dropout_rate)
         self.dropout_enabled = True       # False: deterministic training step (no dropout)
         self.cfg = dict(
             idim=idim, odim=odim, adim=adim, aheads=aheads, positionwise_layer_type=positionwise_layer_type,
@@ -388,11 +391,6 @@ class FeedForwardTransformer(nn.Module):
         `_forward_train`) and dropout follows the constructor's rates (`dropout_enabled = False` turns it off);
         under `torch.no_grad()` / `eval()` it is the plain value (evaluator path, run/train_decode.py:42-57)."""
         if self.training and torch.is_grad_enabled():
-            if self.postnet is not None:
-                raise NotImplementedError(
-                    "training with postnet_layers > 0 is not built (DESIGN.md §7: the repaired PostNet's BatchNorm takes "
-                    "its training statistics over padded frames, which the packed layout does not hold); construct "
-                    "the model with postnet_layers=0, or evaluate under torch.no_grad()")
             return self._forward_train(packed if packed is not None else self.pack_batch(xs, ilens, ys, olens, ds, ps, es))
         if xs is None:
             raise ValueError("`packed=` batches are for the training path (train mode, grad enabled)")

@@ -17,7 +17,7 @@ Different on purpose:
   world-th minibatch;
 * plots, TensorBoard and attention figures are left to the caller (`model.calculate_all_attentions` is there).
 
-    python -m fastspeech2_amd.run.train_decode --synthetic 256 --outdir exp/demo --epochs 2 --postnet-layers 0
+    python -m fastspeech2_amd.run.train_decode --synthetic 256 --outdir exp/demo --epochs 2
 """
 import argparse
 import json

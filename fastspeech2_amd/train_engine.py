@@ -102,14 +102,12 @@ class TrainEngine:
         self.dk = d // self.h
         if self.dk not in (32, 64, 96, 128):
             raise NotImplementedError("head dim %d: the attention kernels support 32/64/96/128" % self.dk)
-        if cfg["postnet_layers"] != 0:
-            raise NotImplementedError("training with a PostNet (training-mode BatchNorm) is not built: "
-                                      "set postnet_layers=0")
         if cfg["reduction_factor"] != 1:
             raise NotImplementedError("reduction_factor != 1")
         if not cfg["use_masking"]:
             raise NotImplementedError("use_masking=False")
         self.P: Dict[str, torch.nn.Parameter] = dict(model.named_parameters())
+        self.buffers: Dict[str, torch.Tensor] = dict(model.named_buffers())      # BatchNorm running statistics
         for k, p in self.P.items():
             if p.device != self.dev or p.dtype != torch.float32 or not p.is_contiguous():
                 raise hip.HipError("parameter %s must be a contiguous fp32 tensor on %s" % (k, self.dev))
@@ -180,9 +178,21 @@ class TrainEngine:
         if wp.shape[-1] != 1 or we.shape[-1] != 1:
             raise NotImplementedError("pitch/energy embed kernel size must be 1")
         self.pdim, self.edim = wp.shape[1], we.shape[1]
+        # repaired PostNet (network/fastspeech2.py:13-54): conv (no bias) -> BatchNorm -> tanh -> dropout
+        self.post = []
+        n = cfg["postnet_layers"]
+        if n and self.odim % self.epv:
+            raise NotImplementedError("PostNet training needs odim %% %d == 0" % self.epv)
+        for j in range(n):
+            pre = "postnet.postnet.%d." % j
+            w = self.P[pre + "0.weight"]
+            last = j == n - 1
+            self.post.append(dict(p=pre, w=_Weight([w], self.tdt, self.dev, pad_n=self.odim_pad if last else 0),
+                                  cin=w.shape[1], cout=w.shape[0], k=w.shape[2], bn=bool(cfg.get("use_batch_norm", True)),
+                                  last=last, site=(3 << 16) + j))
 
     def _all_weights(self) -> List[_Weight]:
-        out = [self.w_out]
+        out = [self.w_out] + [L["w"] for L in self.post]
         for L in self.enc_layers + self.dec_layers:
             out += [L[k] for k in ("wqkv", "wo", "w1", "w2", "wc_x", "wc_a") if k in L]
         for pr in (self.dur_pred, self.pitch_pred, self.energy_pred):
@@ -211,7 +221,12 @@ class TrainEngine:
         """Flat fp32 gradient buffer, bucketed in backward-completion order."""
         cfg = self.cfg
         va = "variance_adaptor."
-        buckets: List[List[str]] = [["feat_out.weight", "feat_out.bias"]]
+        buckets: List[List[str]] = [[]]
+        for L in reversed(self.post):
+            buckets[0].append(L["p"] + "0.weight")
+            if L["bn"]:
+                buckets[0] += [L["p"] + "1.weight", L["p"] + "1.bias"]
+        buckets[0] += ["feat_out.weight", "feat_out.bias"]
         for L in reversed(self.dec_layers):
             buckets.append(self._layer_param_names(L, cfg["decoder_concat_after"]))
         adaptor = []
@@ -419,7 +434,7 @@ class TrainEngine:
             self._pack_groups = (
                 _PackGroup(lw(self.enc_layers) + [c["w"] for c in self.dur_pred["convs"]], self.dev),
                 _PackGroup([c["w"] for pr in (self.pitch_pred, self.energy_pred) for c in pr["convs"]] +
-                           lw(self.dec_layers) + [self.w_out], self.dev))
+                           lw(self.dec_layers) + [self.w_out] + [L["w"] for L in self.post], self.dev))
         with torch.cuda.stream(side):
             self._pack_layers(self.enc_layers, self.cfg["encoder_concat_after"])      # bias concatenation, concat_after split
             self._pack_groups[0].launch(self.code)
@@ -635,6 +650,67 @@ class TrainEngine:
                 dparts = self._gemm(dpre, w.bwd, None, M, cin, w.N, w.k, seg=sg, out_f32=True,
                                     ksplit=self._ksplit(M, cin, w.N, w.k))
 
+    # ------------------------------------------------------------------ PostNet (training-mode BatchNorm)
+    BN_EPS, BN_MOMENTUM = 1e-5, 0.1          # nn.BatchNorm1d defaults
+
+    def _postnet_fwd(self, before, seg, M):
+        """after = before + postnet(before) (network/fastspeech2.py:222-225); BatchNorm takes its statistics over
+        the packed frames of the batch and updates running_mean / running_var / num_batches_tracked as
+        nn.BatchNorm1d does in train() mode."""
+        P, lib = self.P, hip.load()
+        rate = self._rate("postnet")
+        cur = self._empty((M, self.odim))
+        call("fs2_cast", ptr(before), ptr(cur), M * self.odim, self.code, stream())
+        recs, after = [], None
+        for L in self.post:
+            w = L["w"]
+            y = self._gemm(cur, w.fwd, None, M, L["cout"], L["cin"], L["k"], seg=seg if L["k"] > 1 else None, out_f32=True,
+                           tag="postnet")
+            stats = None
+            if L["bn"]:
+                stats = self._empty((3, L["cout"]), torch.float32)
+                ws = self._ws(lib.fs2_bn_workspace(M, L["cout"]))
+                call("fs2_bn_stats", ptr(y), ptr(stats), ptr(ws), M, L["cout"], self.BN_EPS, stream())
+                rm, rv = self.buffers[L["p"] + "1.running_mean"], self.buffers[L["p"] + "1.running_var"]
+                rm.mul_(1.0 - self.BN_MOMENTUM).add_(stats[0], alpha=self.BN_MOMENTUM)
+                rv.mul_(1.0 - self.BN_MOMENTUM).add_(stats[2], alpha=self.BN_MOMENTUM * M / max(M - 1, 1))
+                self.buffers[L["p"] + "1.num_batches_tracked"].add_(1)
+            gam = P[L["p"] + "1.weight"] if L["bn"] else None
+            bet = P[L["p"] + "1.bias"] if L["bn"] else None
+            recs.append(dict(inp=cur, y=y, stats=stats))
+            if L["last"]:
+                after = self._empty((M, self.odim), torch.float32)
+                call("fs2_bn_apply", ptr(y), ptr(stats), ptr(gam), ptr(bet), 0, ptr(before), self.odim, ptr(after),
+                     self.odim, None, 0, M, L["cout"], self.code, self.seed, L["site"], rate, stream())
+            else:
+                nxt = self._empty((M, L["cout"]))
+                call("fs2_bn_apply", ptr(y), ptr(stats), ptr(gam), ptr(bet), 1, None, 0, None, 0, ptr(nxt), L["cout"], M,
+                     L["cout"], self.code, self.seed, L["site"], rate, stream())
+                cur = nxt
+        return after, recs
+
+    def _postnet_bwd(self, recs, dafter, seg, M):
+        """dafter: gradient of `after` (fp32).  Fills the PostNet gradients; returns the gradient wrt the PostNet input
+        (fp32 [M, odim]; the residual path `after = before + ...` is added by the caller)."""
+        P, G, lib = self.P, self.G, hip.load()
+        rate = self._rate("postnet")
+        dout = dafter
+        for L, r in zip(reversed(self.post), reversed(recs)):
+            w = L["w"]
+            C = L["cout"]
+            ldt = self.odim_pad if L["last"] else C
+            dy = torch.zeros((M, ldt), device=self.dev, dtype=self.tdt) if ldt != C else self._empty((M, C))
+            gam = P[L["p"] + "1.weight"] if L["bn"] else None
+            bet = P[L["p"] + "1.bias"] if L["bn"] else None
+            ws = self._ws(lib.fs2_bn_workspace(M, C)) if L["bn"] else None
+            call("fs2_bn_bwd", ptr(r["y"]), ptr(r["stats"]), ptr(gam), ptr(bet), 0 if L["last"] else 1, ptr(dout), C,
+                 ptr(G[L["p"] + "1.weight"]) if L["bn"] else None, ptr(G[L["p"] + "1.bias"]) if L["bn"] else None, ptr(dy),
+                 ldt, ptr(ws), M, C, self.code, self.seed, L["site"], rate, stream())
+            sg = seg if L["k"] > 1 else None
+            self._wgrad(dy, r["inp"], G[L["p"] + "0.weight"], sg, M, C, L["cin"], L["k"], ldy=ldt, tag="wgrad_postnet")
+            dout = self._gemm(dy, w.bwd, None, M, L["cin"], ldt, L["k"], seg=sg, out_f32=True, tag="dgrad_postnet")
+        return dout
+
     # ------------------------------------------------------------------ one step
     def forward(self, ids, ilens, olens, ds, ps, es, ys):
         """ids int64 [Mp], ds int32 [Mp], ps fp32 [Mf,4], es fp32 [Mf,1], ys fp32 [Mf,odim] — packed, on the device.
@@ -717,12 +793,17 @@ class TrainEngine:
         z32, zt, dec_saved = self._stack_fwd(self.dec_layers, "decoder.", dec_pre, cfg["decoder_concat_after"], y32, yt,
                                              seg_f, cu_frames, B, max_ol, Mf)
         before = self._gemm(zt, self.w_out.fwd, P["feat_out.bias"], Mf, self.odim, d, 1, out_f32=True)
-        saved = dict(B=B, Mp=Mp, Mf=Mf, max_il=max_il, max_ol=max_ol, ids=ids, ds=ds, ps=ps, es=es, ys=ys,
+        after, post_saved = self._postnet_fwd(before, seg_f, Mf) if self.post else (None, None)
+        saved = dict(B=B, Mp=Mp, Mf=Mf, max_il=max_il, max_ol=max_ol, ids=ids, ds=ds, ps=ps, es=es, ys=ys, after=after,
+                     post=post_saved,
                      cu_phone=cu_phone, cu_frames=cu_frames, seg_p=seg_p, seg_f=seg_f, pos_p=pos_p, pos_f=pos_f,
                      dur_used=dur_used, cum=cum, enc=enc_saved, dec=dec_saved, dur=dur_saved, pitch=pitch_saved,
                      energy=energy_saved, hst=hst, hs_lrt=hs_lrt, zt=zt, before=before, logd=logd, pitch_out=pitch,
                      energy_out=energy, xscale=xscale, seed=self.seed, drop_on=self.drop_on, keep=(olens_dev, lr_index, hs_lr32, x32, y32, z32))
-        return dict(before=before, log_durations=logd.view(-1), pitch=pitch, energy=energy), saved
+        outs = dict(before=before, log_durations=logd.view(-1), pitch=pitch, energy=energy)
+        if after is not None:
+            outs["after"] = after
+        return outs, saved
 
     def backward(self, s, upstream: Optional[torch.Tensor] = None):
         """Fills self.G (all parameter gradients, fp32) for loss = L1(before, ys) + MSE(logd, log(ds+1)) +
@@ -744,8 +825,21 @@ class TrainEngine:
             bi += 1
         # ---- mel loss -> feat_out
         dbt = self._empty((Mf, self.odim_pad))
-        call("fs2_loss_grad", ptr(s["before"]), ptr(s["ys"]), None, 0, 1.0 / (Mf * self.odim), up, None, ptr(dbt), Mf,
-             self.odim, self.odim_pad, self.code, stream())
+        if self.post:       # loss = L1(after) + L1(before), after = before + postnet(before)
+            dbefore = self._empty((Mf, self.odim), torch.float32)
+            call("fs2_loss_grad", ptr(s["before"]), ptr(s["ys"]), None, 0, 1.0 / (Mf * self.odim), up, ptr(dbefore), None,
+                 Mf, self.odim, self.odim, self.code, stream())
+            dafter = self._empty((Mf, self.odim), torch.float32)
+            call("fs2_loss_grad", ptr(s["after"]), ptr(s["ys"]), None, 0, 1.0 / (Mf * self.odim), up, ptr(dafter), None,
+                 Mf, self.odim, self.odim, self.code, stream())
+            dx0 = self._postnet_bwd(s["post"], dafter, s["seg_f"], Mf)
+            dbefore.add_(dafter).add_(dx0)
+            if self.odim_pad != self.odim:
+                dbt.zero_()
+            dbt[:, :self.odim].copy_(dbefore)
+        else:
+            call("fs2_loss_grad", ptr(s["before"]), ptr(s["ys"]), None, 0, 1.0 / (Mf * self.odim), up, None, ptr(dbt), Mf,
+                 self.odim, self.odim_pad, self.code, stream())
         self._wgrad(dbt, s["zt"], G["feat_out.weight"], None, Mf, self.odim, d, 1, ldy=self.odim_pad,
                     dbias=G["feat_out.bias"])
         dz = self._gemm(dbt, self.w_out.bwd, None, Mf, d, self.odim_pad, 1, out_f32=True)

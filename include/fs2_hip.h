@@ -306,6 +306,26 @@ int fs2_pack_weight(const float* src, void* fwd, void* bwd, int N, int C, int k,
 int fs2_pack_weights(const fs2_pack_desc* desc, const int* start, int n, int total_blocks, int dtype,
                      hipStream_t stream);
 
+/* Training-mode nn.BatchNorm1d of the repaired PostNet (network/fastspeech2.py:13-54: Conv1d(bias=False) -> BatchNorm1d
+ * -> Tanh (not on the last layer) -> Dropout; applied at :222-225) over packed frames: y [M, C] fp32 is a conv output
+ * of the whole batch, statistics per channel over its M rows.
+ * fs2_bn_stats: stats[3][C] = mean, 1 / sqrt(var + eps), biased variance (the caller folds them into running_mean /
+ *   running_var).  workspace: fs2_bn_workspace(M, C) bytes.
+ * fs2_bn_apply: out = dropout(act(gamma * (y - mean) * rstd + beta)) (+ res [M, ldr] fp32), act 0 none / 1 tanh, written
+ *   as `dtype` [M, ldt] and / or fp32 [M, ldf]; dropout element (site, row, col) as in the other training kernels;
+ *   stats NULL = no BatchNorm (use_batch_norm=False).
+ * fs2_bn_bwd: backward of fs2_bn_apply from y and the statistics alone: dout [M, ldd] fp32 is the gradient of its output;
+ *   dgamma = sum dz * xhat, dbeta = sum dz (dz = dout through dropout and tanh), dy_t [M, ldt] (`dtype`) =
+ *   gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)): the operand of the conv's gradient GEMMs. */
+long long fs2_bn_workspace(int M, int C);
+int fs2_bn_stats(const float* y, float* stats, float* workspace, int M, int C, float eps, hipStream_t stream);
+int fs2_bn_apply(const float* y, const float* stats, const float* gamma, const float* beta, int act, const float* res,
+                 int ldr, float* out_f32, int ldf, void* out_t, int ldt, int M, int C, int dtype, unsigned seed,
+                 unsigned site, float rate, hipStream_t stream);
+int fs2_bn_bwd(const float* y, const float* stats, const float* gamma, const float* beta, int act, const float* dout,
+               int ldd, float* dgamma, float* dbeta, void* dy_t, int ldt, float* workspace, int M, int C, int dtype,
+               unsigned seed, unsigned site, float rate, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

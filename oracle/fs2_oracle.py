@@ -249,6 +249,33 @@ def postnet(sd, cfg, before: torch.Tensor) -> torch.Tensor:
     return y.squeeze(0).t()
 
 
+def postnet_train(sd, cfg, befores, running=None):
+    """The repaired PostNet in train() mode (dropout off) on a batch: `befores` is a list of (T_b, odim) tensors, one per
+    utterance.  Every conv sees one utterance at a time (zero padding at its edges, as in the padded reference batch
+    once padding frames are excluded); nn.BatchNorm1d takes its statistics over the frames of ALL utterances.  Returns
+    the list of residual branches; `running` (dict) receives the updated running_mean / running_var
+    (momentum 0.1, unbiased variance) when given.  Padded frames do not exist here: the literal reference would also
+    average over them (it cannot run at all) - parity of this piece is unpinned."""
+    n = cfg["postnet_layers"]
+    lens = [int(b.shape[0]) for b in befores]
+    ys = [b.t().unsqueeze(0) for b in befores]
+    for j in range(n):
+        w = sd["postnet.postnet.%d.0.weight" % j]
+        ys = [F.conv1d(y, w, None, padding=(w.shape[-1] - 1) // 2) for y in ys]
+        if cfg["use_batch_norm"]:
+            p = "postnet.postnet.%d.1." % j
+            allf = torch.cat(ys, 2)
+            rm = sd[p + "running_mean"].detach().clone()
+            rv = sd[p + "running_var"].detach().clone()
+            allf = F.batch_norm(allf, rm, rv, sd[p + "weight"], sd[p + "bias"], True, 0.1, BN_EPS)
+            if running is not None:
+                running[p + "running_mean"], running[p + "running_var"] = rm, rv
+            ys = list(torch.split(allf, lens, 2))
+        if j != n - 1:
+            ys = [torch.tanh(y) for y in ys]
+    return [y.squeeze(0).t() for y in ys]
+
+
 def decode(sd, cfg, hs: torch.Tensor, attens=None, return_before: bool = False):
     """decoder stack + feat_out (+ repaired postnet): network/fastspeech2.py:218-225."""
     zs = fft_stack(hs, sd, "decoder.", has_embedding=False, attens=attens, **_dec_kw(cfg))
@@ -349,8 +376,9 @@ def train_grads(sd, cfg, xs, ilens, ys, olens, ds, ps, es):
     """Loss of `train_loss` with autograd through the functional restatement: returns
     (loss terms, {parameter name: d loss / d parameter}).  What `loss.backward()` leaves in
     `.grad` in run/train_decode.py:94-97 (accum_grad = 1), dropout off (eval-mode modules),
-    PostNet-free models only (training-mode BatchNorm statistics are not restated)."""
-    assert cfg["use_masking"] and cfg["postnet_layers"] == 0
+    With a PostNet the BatchNorm statistics couple the utterances (`postnet_train`): the graph of the whole batch is
+    kept and differentiated once; `terms["running"]` then holds the updated running statistics."""
+    assert cfg["use_masking"]
     leaf = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd.items()}
     B = len(ilens)
     n_mel = sum(int(olens[b]) for b in range(B)) * cfg["odim"]
@@ -358,6 +386,8 @@ def train_grads(sd, cfg, xs, ilens, ys, olens, ds, ps, es):
     n_fr = sum(int(olens[b]) for b in range(B))
     terms = dict(l1_loss=0.0, duration_loss=0.0, pitch_loss=0.0, energy_loss=0.0)
     total = 0.0
+    has_post = cfg["postnet_layers"] != 0
+    befores, pending = [], []
     for b in range(B):
         il, ol = int(ilens[b]), int(olens[b])
         hs = encode(leaf, cfg, xs[b, :il])
@@ -367,17 +397,33 @@ def train_grads(sd, cfg, xs, ilens, ys, olens, ds, ps, es):
         p_outs = variance_predict(hs_lr, leaf, "pitch")
         e_outs = variance_predict(hs_lr, leaf, "energy")
         hs_va = hs_lr + (variance_embed(ps[b, :ol], leaf, "pitch") + variance_embed(es[b, :ol], leaf, "energy"))
-        mel = decode(leaf, cfg, hs_va)
+        if has_post:
+            zs = fft_stack(hs_va, leaf, "decoder.", has_embedding=False, attens=None, **_dec_kw(cfg))
+            mel = F.linear(zs, leaf["feat_out.weight"], leaf["feat_out.bias"]).view(-1, cfg["odim"])
+            befores.append(mel)
+        else:
+            mel = decode(leaf, cfg, hs_va)
         tgt = torch.log(ds[b, :il].float() + DUR_OFFSET)
         parts = dict(l1_loss=(mel - ys[b, :ol]).abs().sum() / n_mel,
                      duration_loss=((logd - tgt) ** 2).sum() / n_dur,
                      pitch_loss=((p_outs - ps[b, :ol]) ** 2).sum() / (n_fr * p_outs.shape[-1]),
                      energy_loss=((e_outs - es[b, :ol]) ** 2).sum() / (n_fr * e_outs.shape[-1]))
         loss_b = sum(parts.values())
-        loss_b.backward()                      # per utterance: keeps the graph small
+        if has_post:
+            pending.append(loss_b)
+        else:
+            loss_b.backward()                      # per utterance: keeps the graph small
         for k, v in parts.items():
             terms[k] += float(v.detach())
         total += float(loss_b.detach())
+    if has_post:                                   # network/fastspeech2.py:222-225, 271-274
+        running = {}
+        res = postnet_train(leaf, cfg, befores, running)
+        l1_after = sum(((bf + r) - ys[b, :int(olens[b])]).abs().sum() for b, (bf, r) in enumerate(zip(befores, res))) / n_mel
+        (sum(pending) + l1_after).backward()
+        terms["l1_loss"] += float(l1_after.detach())
+        total += float(l1_after.detach())
+        terms["running"] = running
     terms["loss"] = total
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()
              if v.dtype.is_floating_point}

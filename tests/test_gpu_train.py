@@ -129,6 +129,55 @@ def test_ragged_batch_gradients_match_oracle(name, ilens):
     assert (want - got).abs().max().item() <= 2 * GRAD_TOL * max(want.abs().max().item(), 1e-2)
 
 
+@pytest.mark.parametrize("name", ["postnet_tiny_bn", "postnet_tiny_nobn"])
+def test_postnet_training_gradients_match_oracle(name):
+    """Training with the repaired PostNet (network/fastspeech2.py:222-225, :271-274): loss, every gradient and the
+    BatchNorm running statistics against the oracle's autograd through torch's train()-mode batch_norm over the frames
+    of the batch (dropout off).  Parity vs the literal reference is unpinned here: its PostNet cannot run (D7)."""
+    _, meta = helpers.load_golden(name)
+    cfg = helpers.oracle_cfg(meta)
+    sd = helpers.golden_state_dict(meta)
+    xs, il, ys, ol, ds, ps, es = _ragged_batch(cfg, 12, [23, 4, 37, 1])   # (seeds 11, 14: a ReLU gate of the tiny pitch predictor sits on zero)
+    terms, ref = fs2_oracle.train_grads(sd, cfg, xs, il, ys, ol, ds, ps, es)
+    model = _model(meta)
+    loss = model(xs, il, ys, ol, ds, ps, es)
+    (loss * 0.5).backward()
+    assert abs(loss.item() - terms["loss"]) <= 2e-5 * max(1.0, terms["loss"])
+    for k, p in model.named_parameters():
+        want = 0.5 * ref[k].double()
+        got = p.grad.detach().cpu().double()
+        tol = GRAD_TOL * max(want.abs().max().item(), 1e-2)
+        assert (want - got).abs().max().item() <= tol, (k, (want - got).abs().max().item(), want.abs().max().item())
+    bufs = dict(model.named_buffers())
+    for k, want in terms.get("running", {}).items():
+        got = bufs[k].cpu()
+        assert (want - got).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), k
+    if cfg["use_batch_norm"]:
+        assert int(bufs["postnet.postnet.0.1.num_batches_tracked"]) == 1
+        # eval() after the step uses the UPDATED running statistics (the engine's folded weights are rebuilt)
+        model.eval()
+        with torch.no_grad():
+            ev = model(xs, il, ys, ol, ds, ps, es).item()
+        sd2 = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        want_ev = fs2_oracle.train_loss(sd2, cfg, xs, il, ys, ol, ds, ps, es)["loss"]
+        assert abs(ev - want_ev) <= 5e-5 * max(1.0, want_ev)
+    # dropout on (rate 0.5 after every PostNet layer): another loss, finite gradients; bf16 runs
+    model.train()
+    model.dropout_enabled = True
+    model.zero_grad()
+    l2 = model(xs, il, ys, ol, ds, ps, es)
+    l2.backward()
+    assert math.isfinite(l2.item()) and abs(l2.item() - loss.item()) > 1e-6
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    mb = _model(meta, "bf16")
+    lb = mb(xs, il, ys, ol, ds, ps, es)
+    lb.backward()
+    assert abs(lb.item() - terms["loss"]) <= 0.05 * max(1.0, terms["loss"])
+    g = dict(mb.named_parameters())["postnet.postnet.0.0.weight"].grad.cpu().double()
+    w = ref["postnet.postnet.0.0.weight"].double()
+    assert (g - w).abs().max().item() <= 0.1 * max(w.abs().max().item(), 1e-2)
+
+
 def test_bf16_gradients_track_fp32():
     _, meta = helpers.load_golden("train_tiny_conv3_mixed")
     cfg = helpers.oracle_cfg(meta)

@@ -102,13 +102,14 @@ def test_same_seed_same_init_as_reference(name):
         assert torch.equal(ours[k], ref[k]), k
 
 
-def test_training_with_a_postnet_is_refused_before_anything_runs():
-    """param/fastspeech.yaml has postnet_layers: 5; PostNet training is not built and must say so
-    instead of handing back a loss without a backward."""
+def test_training_on_cpu_fails_loudly_with_a_postnet_too():
+    """param/fastspeech.yaml has postnet_layers: 5; its training step exists (tests/test_gpu_train.py) and, like every
+    other path, has no CPU implementation: a CPU model must say so instead of handing back a loss without a backward."""
+    from fastspeech2_amd.hip import HipError
     m = FeedForwardTransformer(10, 8, adim=32, aheads=2, elayers=1, dlayers=1, eunits=32, dunits=32, postnet_layers=2,
                                postnet_chans=8)
     m.train()
     z = torch.zeros
-    with pytest.raises(NotImplementedError, match="postnet_layers"):
+    with pytest.raises(HipError):
         m(z(1, 3, dtype=torch.long), torch.tensor([3]), z(1, 3, 8), torch.tensor([3]), torch.ones(1, 3, dtype=torch.long),
           z(1, 3, 4), z(1, 3, 1))
