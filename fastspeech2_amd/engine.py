@@ -378,7 +378,7 @@ class Engine:
         with span("fs2.frame_phase"):
             return self.frame_phase(ctx, ps, es, pitch_control, energy_control)
 
-    def phone_phase(self, ids, ilens, duration_control=1.0, ds=None, want_attention=False) -> Dict[str, object]:
+    def phone_phase(self, ids, ilens, duration_control=1.0, ds=None, want_attention=False, static=None) -> Dict[str, object]:
         """Phone-level half: embedding, encoder stack, duration predictor, LengthRegulator planning.
         Everything is enqueued on the current stream; the B+1 frame offsets are copied to pinned host
         memory asynchronously and an event marks the end (no host wait here)."""
@@ -387,9 +387,12 @@ class Engine:
         ilens = [int(v) for v in ilens]
         Mp = int(sum(ilens))
         assert ids.numel() == Mp and ids.dtype == torch.int64 and ids.device.type == "cuda"
-        cu_p = np.zeros(B + 1, np.int32)
-        cu_p[1:] = np.cumsum(ilens)
-        cu_phone = torch.from_numpy(cu_p).to(dev, non_blocking=True)
+        if static is None:
+            cu_p = np.zeros(B + 1, np.int32)
+            cu_p[1:] = np.cumsum(ilens)
+            cu_phone = torch.from_numpy(cu_p).to(dev, non_blocking=True)
+        else:           # under HIP graph capture (GraphedInference): no host memory is allocated or read in here
+            cu_phone = static["cu_phone"]
         max_il = max(ilens) if B else 0
         pe = self._pe_table(max(max_il, 1))
         seg_p = self._empty((max(Mp, 1), 2), dtype=torch.int32)
@@ -421,10 +424,12 @@ class Engine:
         cu_frames = self._empty((B + 1,), dtype=torch.int32)
         call("fs2_lr_plan", ptr(dur_in), ptr(cu_phone), float(duration_control), ptr(dur_used), ptr(cum),
              ptr(olens_dev), ptr(cu_frames), B, stream())
-        cu_host = torch.empty((B + 1,), dtype=torch.int32, pin_memory=True)
+        cu_host = torch.empty((B + 1,), dtype=torch.int32, pin_memory=True) if static is None else static["cu_host"]
         cu_host.copy_(cu_frames, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
+        done = None
+        if static is None:
+            done = torch.cuda.Event()
+            done.record()
         return dict(B=B, Mp=Mp, ilens=ilens, cu_phone=cu_phone, hs32=hs32, cum=cum, cu_frames=cu_frames,
                     cu_host=cu_host, done=done, dur_used=dur_used, dur_pred=dur_pred, logd=logd, enc_att=enc_att,
                     stream=torch.cuda.current_stream(), keep=(ids, dur_in, olens_dev))
@@ -434,14 +439,17 @@ class Engine:
         feat_out.  Waits (host) for the phone phase's frame offsets — the one synchronisation."""
         dev, d = self.dev, self.d
         B, Mp = ctx["B"], ctx["Mp"]
-        cur = torch.cuda.current_stream()
-        if ctx["stream"] != cur:                # phone phase ran on another stream: order + keep memory alive
-            cur.wait_event(ctx["done"])
-            for t in (ctx["cu_phone"], ctx["hs32"], ctx["cum"], ctx["cu_frames"], ctx["dur_used"], ctx["dur_pred"],
-                      ctx["logd"]):
-                t.record_stream(cur)
-        ctx["done"].synchronize()
-        cu_f = ctx["cu_host"].numpy()
+        if "cu_f" in ctx:                       # frame offsets already on the host (GraphedInference): no wait in here
+            cu_f = ctx["cu_f"]
+        else:
+            cur = torch.cuda.current_stream()
+            if ctx["stream"] != cur:            # phone phase ran on another stream: order + keep memory alive
+                cur.wait_event(ctx["done"])
+                for t in (ctx["cu_phone"], ctx["hs32"], ctx["cum"], ctx["cu_frames"], ctx["dur_used"], ctx["dur_pred"],
+                          ctx["logd"]):
+                    t.record_stream(cur)
+            ctx["done"].synchronize()
+            cu_f = ctx["cu_host"].numpy()
         cu_phone, cu_frames, hs32, cum = ctx["cu_phone"], ctx["cu_frames"], ctx["hs32"], ctx["cum"]
         if "cu_slice" in ctx:                   # one batch of a grouped phone phase: rebase the frame offsets
             u0, u1 = ctx["cu_slice"]
@@ -601,3 +609,86 @@ class Engine:
         out = self._empty((B, Tmax, C), dtype=torch.float32)
         call("fs2_unpack_padded", ptr(packed), ptr(cu), ptr(out), B, Tmax, C, stream())
         return out
+
+
+class GraphedInference:
+    """Batch-1 `inference` (network/fastspeech2.py:297-302) replayed from HIP graphs.
+
+    One utterance is ~100 kernel launches for ~0.3 ms of GPU time: issued one by one from Python the call takes about
+    1 ms.  Here the two halves of `Engine.forward` are captured once per shape - the phone-level half per phone count
+    Tp, the frame-level half per (Tp, frame count Tm) - and replayed: a call is a copy of the ids into the graph's input
+    buffer, one replay, the read of Tm (the forward's one synchronisation, as before), a second replay.  The kernels,
+    their arguments and their order are those of `Engine.forward`, so the results are bit-identical to it.
+    A shape seen for the first time runs eagerly (that run is also the warm-up the capture needs) and is captured right
+    after; at most `max_graphs` frame-level graphs are kept (least recently used first out).  The returned tensors live
+    in the graph's memory: they are valid until the next call with the same shape (clone what must live longer)."""
+
+    def __init__(self, engine: "Engine", max_graphs: int = 64):
+        import collections
+        self.eng = engine
+        self.max_graphs = max_graphs
+        self.phone = collections.OrderedDict()
+        self.frame = collections.OrderedDict()
+        self.hits = self.misses = 0
+
+    def _capture_phone(self, Tp, dc):
+        eng, dev = self.eng, self.eng.dev
+        ent = dict(ids=torch.zeros((Tp,), dtype=torch.int64, device=dev),
+                   static=dict(cu_phone=torch.tensor([0, Tp], dtype=torch.int32, device=dev),
+                               cu_host=torch.zeros((2,), dtype=torch.int32).pin_memory()))
+        eng._pe_table(Tp)
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            ent["ctx"] = eng.phone_phase(ent["ids"], [Tp], dc, static=ent["static"])
+        ent["graph"] = g
+        return ent
+
+    def _capture_frame(self, P, Tm, pc, ec):
+        eng = self.eng
+        ctx = dict(P["ctx"])
+        ctx["cu_f"] = np.array([0, Tm], np.int32)
+        eng._pe_table(max(Tm, 1))
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            out = eng.frame_phase(ctx, None, None, pc, ec)
+        return dict(graph=g, out=out)
+
+    def __call__(self, ids: torch.Tensor, duration_control: float = 1.0, pitch_control: float = 1.0,
+                 energy_control: float = 1.0) -> Dict[str, object]:
+        eng = self.eng
+        Tp = int(ids.numel())
+        dc, pc, ec = float(duration_control), float(pitch_control), float(energy_control)
+        P = self.phone.get((Tp, dc))
+        if P is None:                              # first sight of this phone count: eager run, then capture
+            self.misses += 1
+            ids = ids.to(eng.dev, torch.int64).contiguous()
+            out = eng.forward(ids, [Tp], duration_control=dc, pitch_control=pc, energy_control=ec)
+            self.phone[(Tp, dc)] = self._capture_phone(Tp, dc)
+            while len(self.phone) > self.max_graphs:
+                old = self.phone.popitem(last=False)[0]
+                for k in [k for k in self.frame if k[:2] == old]:
+                    del self.frame[k]
+            return out
+        self.phone.move_to_end((Tp, dc))
+        P["ids"].copy_(ids, non_blocking=True)
+        P["graph"].replay()
+        torch.cuda.current_stream().synchronize()  # the frame count: the one synchronisation of a forward
+        Tm = int(P["static"]["cu_host"][1])
+        key = (Tp, dc, Tm, pc, ec)
+        F = self.frame.get(key)
+        if F is None:                              # first sight of this frame count: eager frame phase, then capture
+            self.misses += 1
+            ctx = dict(P["ctx"])
+            ctx["cu_f"] = np.array([0, Tm], np.int32)
+            out = eng.frame_phase(ctx, None, None, pc, ec)
+            out = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+            self.frame[key] = self._capture_frame(P, Tm, pc, ec)
+            while len(self.frame) > self.max_graphs:
+                self.frame.popitem(last=False)
+            return out
+        self.hits += 1
+        self.frame.move_to_end(key)
+        F["graph"].replay()
+        return F["out"]

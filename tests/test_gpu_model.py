@@ -434,3 +434,28 @@ def test_pipelined_forward_equals_serial():
             assert torch.equal(a["cu_frames"], b["cu_frames"]) and torch.equal(a["cu_phone"], b["cu_phone"])
             assert (a["mel"] - b["mel"]).abs().max().item() <= 1e-4
             assert (a["enc_out"] - b["enc_out"]).abs().max().item() <= 1e-4
+
+
+def test_graphed_inference_is_bit_identical_to_the_eager_forward():
+    """`enable_inference_graphs()`: batch-1 inference replayed from HIP graphs (one per phone count, one per frame
+    count) - same kernels and arguments as the eager schedule, so the mel must be equal bit for bit, on first sight of a
+    shape (eager + capture), on replays, with another utterance of the same shape, and across shapes."""
+    z, meta = helpers.load_golden("baseline_4x4")
+    model = build_model(meta, "bf16", "f16x3")
+    rng = np.random.Generator(np.random.PCG64(5))
+    idim = meta["cfg"]["idim"]
+    utts = [torch.from_numpy(rng.integers(1, idim, size=n)) for n in (37, 90, 37, 90, 37)]
+    with torch.no_grad():
+        want = [model.inference(u).cpu() for u in utts]
+        model.enable_inference_graphs(8)
+        for rnd in range(3):
+            for u, w in zip(utts, want):
+                got = model.inference(u).cpu()
+                assert got.shape == w.shape and torch.equal(got, w), (rnd, u.shape)
+        gi = model._graphed
+        assert gi.hits >= 8 and len(gi.phone) == 2
+        # the controls are part of the graph key
+        a = model.inference(utts[0], duration_control=1.3).cpu()
+        model.enable_inference_graphs(0)
+        b = model.inference(utts[0], duration_control=1.3).cpu()
+        assert torch.equal(a, b)
