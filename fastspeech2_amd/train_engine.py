@@ -87,6 +87,7 @@ class _PackGroup:
 
 class TrainEngine:
     SITE_ENC_POS, SITE_DEC_POS = (2 << 16) + 1, (2 << 16) + 2
+    SITE_PITCH_EMB, SITE_ENERGY_EMB = (2 << 16) + 3, (2 << 16) + 4
 
     def __init__(self, model, dtype: str = "fp32"):
         self.dev = hip.require_gpu()
@@ -120,9 +121,6 @@ class TrainEngine:
         # dropout sites (rates of the reference's constructor; 0 disables a site).  model.dropout_enabled = False
         # switches every site off (deterministic step, used for the parity tests against eval-mode goldens)
         self.rates = dict(model.dropout_rates)
-        for k in ("pitch_embed", "energy_embed"):
-            if self.rates.get(k, 0.0) > 0.0:
-                raise NotImplementedError("dropout inside the variance embeddings is not built (reference default 0.0)")
         # dropout masks = hash(seed of the step, site, row, col); the step seed mixes a user seed (`set_seed`), the
         # data-parallel rank (ranks must not draw the same masks) and the step counter (saved in snapshots)
         self.base_seed = 0x5EED
@@ -777,9 +775,24 @@ class TrainEngine:
         pe_f = self._pe_table(max_ol)
         y32 = self._empty((Mf, d), torch.float32)
         yt = self._empty((Mf, d)) if (not dec_pre and self.code != F32) else None
-        vargs = (ptr(hs_lr32), ptr(ps), ptr(es), ptr(P[va + "pitch_embed.conv.conv.weight"]),
-                 ptr(P[va + "pitch_embed.conv.conv.bias"]), ptr(P[va + "energy_embed.conv.conv.weight"]),
-                 ptr(P[va + "energy_embed.conv.conv.bias"]), 1.0, 1.0, ptr(pe_f), ptr(pos_f), xscale)
+        r_pe, r_ee = self._rate("pitch_embed"), self._rate("energy_embed")
+        hs_in = hs_lr32
+        w_pe, b_pe = P[va + "pitch_embed.conv.conv.weight"], P[va + "pitch_embed.conv.conv.bias"]
+        w_ee, b_ee = P[va + "energy_embed.conv.conv.weight"], P[va + "energy_embed.conv.conv.bias"]
+        if r_pe > 0.0 or r_ee > 0.0:
+            # nn.Dropout inside VarianceEmbedding (network/variance_adaptor.py:35-51; reference default 0): the two
+            # embeddings are formed apart ([Mf, 4] x [4, d] and [Mf, 1] x [1, d]), dropped out and added to hs_lr; the
+            # fused kernel then runs with zero embedding weights
+            ep = torch.addmm(b_pe, ps, w_pe.view(d, self.pdim).t())
+            ee = torch.addmm(b_ee, es, w_ee.view(d, self.edim).t())
+            if r_pe > 0.0:
+                call("fs2_dropout", ptr(ep), None, Mf, d, self.seed, self.SITE_PITCH_EMB, r_pe, F32, stream())
+            if r_ee > 0.0:
+                call("fs2_dropout", ptr(ee), None, Mf, d, self.seed, self.SITE_ENERGY_EMB, r_ee, F32, stream())
+            hs_in = hs_lr32 + ep + ee
+            w_pe, b_pe, w_ee, b_ee = (torch.zeros_like(t) for t in (w_pe, b_pe, w_ee, b_ee))
+        vargs = (ptr(hs_in), ptr(ps), ptr(es), ptr(w_pe), ptr(b_pe), ptr(w_ee), ptr(b_ee), 1.0, 1.0, ptr(pe_f),
+                 ptr(pos_f), xscale)
         vtail = (None, ptr(y32), ptr(yt), Mf, d, self.pdim, self.edim, self.code, stream())
         if self.scaled:
             call("fs2_variance_add_posenc_dev", *vargs, ptr(P["decoder.embed.0.alpha"]), *vtail)
@@ -855,14 +868,29 @@ class TrainEngine:
             tmp = self._empty((d,), torch.float32)
             self._colsum(dy, tmp, Mf, d, g_is_t=False, pe=self._pe_table(s["max_ol"]), pos=s["pos_f"])
             torch.sum(tmp, 0, out=G["decoder.embed.0.alpha"])
-        S = torch.cat([s["ps"], s["es"], torch.ones((Mf, 1), device=self.dev)], 1).contiguous()
-        R = self.pdim + self.edim + 1
-        emb = self._empty((R, d), torch.float32)
-        self._colsum(dy, emb, Mf, d, g_is_t=False, S=S, R=R, scale=s["xscale"])
-        G[va + "pitch_embed.conv.conv.weight"].copy_(emb[:self.pdim].t().unsqueeze(-1))
-        G[va + "energy_embed.conv.conv.weight"].copy_(emb[self.pdim:self.pdim + self.edim].t().unsqueeze(-1))
-        G[va + "pitch_embed.conv.conv.bias"].copy_(emb[R - 1])
-        G[va + "energy_embed.conv.conv.bias"].copy_(emb[R - 1])
+        r_pe, r_ee = self._rate("pitch_embed"), self._rate("energy_embed")
+        ones = torch.ones((Mf, 1), device=self.dev)
+        if r_pe > 0.0 or r_ee > 0.0:       # every embedding has its own mask: gradient = column sums of mask o dy
+            for key, vals, dim, site, rate in (("pitch_embed", s["ps"], self.pdim, self.SITE_PITCH_EMB, r_pe),
+                                               ("energy_embed", s["es"], self.edim, self.SITE_ENERGY_EMB, r_ee)):
+                g = dy
+                if rate > 0.0:
+                    g = dy.clone()
+                    call("fs2_dropout", ptr(g), None, Mf, d, self.seed, site, rate, F32, stream())
+                emb = self._empty((dim + 1, d), torch.float32)
+                self._colsum(g, emb, Mf, d, g_is_t=False, S=torch.cat([vals, ones], 1).contiguous(), R=dim + 1,
+                             scale=s["xscale"])
+                G[va + key + ".conv.conv.weight"].copy_(emb[:dim].t().unsqueeze(-1))
+                G[va + key + ".conv.conv.bias"].copy_(emb[dim])
+        else:
+            S = torch.cat([s["ps"], s["es"], ones], 1).contiguous()
+            R = self.pdim + self.edim + 1
+            emb = self._empty((R, d), torch.float32)
+            self._colsum(dy, emb, Mf, d, g_is_t=False, S=S, R=R, scale=s["xscale"])
+            G[va + "pitch_embed.conv.conv.weight"].copy_(emb[:self.pdim].t().unsqueeze(-1))
+            G[va + "energy_embed.conv.conv.weight"].copy_(emb[self.pdim:self.pdim + self.edim].t().unsqueeze(-1))
+            G[va + "pitch_embed.conv.conv.bias"].copy_(emb[R - 1])
+            G[va + "energy_embed.conv.conv.bias"].copy_(emb[R - 1])
         if s["xscale"] != 1.0:
             acc = self._empty((Mf, d), torch.float32)
             call("fs2_scale", ptr(dy), float(s["xscale"]), ptr(acc), Mf * d, stream())

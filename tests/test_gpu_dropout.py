@@ -129,14 +129,15 @@ def test_attention_dropout_forward_backward(dtype):
     assert err <= (5e-5 if dtype == "fp32" else 3e-2) * max(1.0, qr.grad.abs().max().item()), err
 
 
-@pytest.mark.parametrize("name", ["train_tiny_conv9", "train_tiny_conv3_mixed"])
+@pytest.mark.parametrize("name", ["train_tiny_conv9", "train_tiny_conv3_mixed", "postnet_tiny_bn"])
 def test_step_with_dropout_is_consistent(name):
     """With every dropout site on and the step seed pinned, the loss is a fixed function of the weights: its
     directional derivative (central differences) must equal <grad, direction>."""
     _, meta = helpers.load_golden(name)
     idim, odim, kw = helpers.split_cfg(meta["cfg"])
     kw = dict(kw, transformer_enc_dropout_rate=0.1, transformer_enc_positional_dropout_rate=0.1,
-              transformer_enc_atten_dropout_rate=0.1)            # decoder / predictor rates: constructor defaults
+              transformer_enc_atten_dropout_rate=0.1, pitch_embed_dropout=0.2,
+              energy_embed_dropout=0.3)           # decoder / predictor / PostNet rates: constructor defaults
     model = FeedForwardTransformer(idim, odim, **kw)
     model.load_state_dict(helpers.golden_state_dict(meta), strict=True)
     model.to(DEV).train()
