@@ -27,6 +27,9 @@
 
 namespace fs2 {
 
+#ifndef FS2_CONV_PRE
+#define FS2_CONV_PRE 1      // bf16: all LDS fragment reads of a (tap, chunk) step are requested in front of its MFMAs (-1 % per FFN conv launch; 0: per 32-channel half)
+#endif
 constexpr int CG_MAX_TAPS = 9;
 constexpr int CG_HALO = CG_MAX_TAPS - 1;
 constexpr int CG_ROWB = 128;  // bytes per LDS row = one channel chunk
@@ -360,6 +363,41 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
         const unsigned char* xs = smem + xbuf * X_BYTES;
         const unsigned char* ws = smem + XBUFS * X_BYTES + wbuf * W_BYTES;
         const int shift = tap - pad;
+#if FS2_CONV_PRE
+        if constexpr (!SPLIT && sizeof(T) == 2) {
+            // all fragments of the step are requested before its first MFMA
+            frag_t wf[KSTEPS][NT], xf[KSTEPS][MT];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int r = wrow_base + 4 * nt;
+                    wf[ks][nt] = *(const frag_t*)(ws + r * CG_ROWB + (((ks * 4 + g) ^ swz_w(r)) << 4));
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int r = xrow_base + mt * 16 + tap;
+                    xf[ks][mt] = *(const frag_t*)(xs + r * CG_ROWB + (((ks * 4 + g) ^ swz_x(r)) << 4));
+                }
+            }
+            if (need_mask) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (shift < lo[mt] || shift > hi[mt]) {
+#pragma unroll
+                        for (int ks = 0; ks < KSTEPS; ++ks) xf[ks][mt] = frag_zero<T>();
+                    }
+            }
+            mid();
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(wf[ks][nt], xf[ks][mt], acc[mt][nt]);
+            return;
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             frag_t wf[NT], xf[MT];
