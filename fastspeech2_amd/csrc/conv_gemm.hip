@@ -30,6 +30,9 @@ namespace fs2 {
 #ifndef FS2_CONV_PRE
 #define FS2_CONV_PRE 1      // bf16: all LDS fragment reads of a (tap, chunk) step are requested in front of its MFMAs (-1 % per FFN conv launch; 0: per 32-channel half)
 #endif
+#ifndef FS2_CONV_PIN
+#define FS2_CONV_PIN 1      // keep the closing wait + barrier of a step behind its MFMAs (0: where hipcc puts them)
+#endif
 constexpr int CG_MAX_TAPS = 9;
 constexpr int CG_HALO = CG_MAX_TAPS - 1;
 constexpr int CG_ROWB = 128;  // bytes per LDS row = one channel chunk
@@ -494,6 +497,11 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                 if (XDB && next_x) stage_x(nchunk, xcur ^ 1);
             }
             compute(tap, xcur, wcur, []() {});
+#if FS2_CONV_PIN
+            // the MFMAs are register-only: left alone, hipcc hoists the step's closing wait + barrier up to behind the
+            // second MFMA, and the wave then sits in vmcnt(0) with its DMA just issued and 30 MFMAs still to go
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (!DMA) {  // generic path: synchronous register staging of step+1 (odd shapes only)
                 if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
                 if (next_x) stage_x(nchunk, xcur ^ 1);
