@@ -642,6 +642,7 @@ class GraphedInference:
         with torch.cuda.graph(g):
             ent["ctx"] = eng.phone_phase(ent["ids"], [Tp], dc, static=ent["static"])
         ent["graph"] = g
+        ent["pe"] = eng._pe          # the graph holds this table's address: keep it alive if the engine grows a new one
         return ent
 
     def _capture_frame(self, P, Tm, pc, ec):
@@ -653,7 +654,7 @@ class GraphedInference:
         torch.cuda.synchronize()
         with torch.cuda.graph(g):
             out = eng.frame_phase(ctx, None, None, pc, ec)
-        return dict(graph=g, out=out)
+        return dict(graph=g, out=out, pe=eng._pe)
 
     def __call__(self, ids: torch.Tensor, duration_control: float = 1.0, pitch_control: float = 1.0,
                  energy_control: float = 1.0) -> Dict[str, object]:
