@@ -106,6 +106,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_src<0x143, 0xC>(v, 0.f);     // row_bcast:31 into rows 2, 3
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// sum over the 16 lanes of a DPP row, result in all 16 (xor butterfly: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror): four VALU steps for four independent rows of lanes at once
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_src<0xB1, 0xF>(v, 0.f);
+    v += dpp_src<0x4E, 0xF>(v, 0.f);
+    v += dpp_src<0x141, 0xF>(v, 0.f);
+    v += dpp_src<0x140, 0xF>(v, 0.f);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
     const float ninf = -__builtin_inff();
     v = fmaxf(v, dpp_src<0x111, 0xF>(v, ninf));

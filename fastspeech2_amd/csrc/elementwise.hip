@@ -4,6 +4,7 @@
 // All activations are packed ragged matrices [rows, channels], channel-last, fp32 residual stream
 // with an optional low-precision (bf16) copy for the MFMA kernels.
 #include "common.h"
+#include <stdlib.h>
 
 namespace fs2 {
 
@@ -168,80 +169,94 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x
 // energy predictors at frame level, where that fp32 matrix (M x 384) was written only to be read once by
 // rowdot_kernel.  Same arithmetic in the same order as add_layernorm_kernel + rowdot_kernel.  Inference only (the
 // training step keeps the LayerNorm output for the head's weight gradient).
-// One wave per LRD_ROWS consecutive rows: the LayerNorm affine and the head's weight rows are loaded once per wave
-// (they were re-read for every row: (2 + NOUT) x C x 4 bytes of L1/L2 traffic per 4 C bytes of HBM), and all rows'
-// loads are issued before the first reduction.
+// One wave per LRD_ROWS = 4 consecutive rows, ONE ROW PER 16-LANE GROUP: a lane holds C / 16 elements of its row, so the
+// 2 + NOUT reductions of a row are four DPP steps inside the group and the four rows reduce in the same instructions
+// (one wave-wide reduction per row and quantity before: 24 seven-step reductions per wave, which bounded the kernel).
+// The head's dot products are taken on the raw row against a_h = w o W_h:
+//   out_h = rstd (sum x a_h - mean sum a_h) + sum b W_h + hb_h.
 constexpr int LRD_ROWS = 4;
 
+// A wave walks its row groups with a grid stride: a_h and the row-independent sums are formed once per wave and stay in
+// registers, and the next group's rows are requested before the current group is reduced.
 template <int NOUT>
 __global__ __launch_bounds__(256) void layernorm_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ b, const float* __restrict__ W,
                                                                const float* __restrict__ hb, float* __restrict__ out, int M,
                                                                int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LRD_ROWS;
-    if (row0 >= M) return;
-    const int cv = C >> 2;
-    constexpr int NV = 2;                     // C <= 512 (the entry point sends wider rows to the generic form)
-    f32x4 v[LRD_ROWS][NV];
+    const int lane = threadIdx.x & 63, sub = lane & 15, quarter = lane >> 4;
+    const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    const int ngroups = (M + LRD_ROWS - 1) / LRD_ROWS;
+    if (wave_id >= ngroups) return;
+    const int cv = C >> 2;                    // f32x4 columns; lane `sub` takes columns sub, sub + 16, ...
+    constexpr int NV = 8;                     // C <= 512 (the entry point sends wider rows to the generic form)
+    f32x4 a[NOUT][NV];
+    float sa[NOUT], sb[NOUT];
 #pragma unroll
-    for (int r = 0; r < LRD_ROWS; ++r) {
-        const size_t roff = (size_t)min(row0 + r, M - 1) * C;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = lane + k * 64;
-            v[r][k] = j < cv ? *(const f32x4*)(x + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    f32x4 ww[NV], bb[NV], wv[NOUT][NV];
+    for (int h = 0; h < NOUT; ++h) sa[h] = sb[h] = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const int j = lane + k * 64;
+        const int j = sub + k * 16;
         const bool ok = j < cv;
-        ww[k] = ok ? *(const f32x4*)(w + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        bb[k] = ok ? *(const f32x4*)(b + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 ww = ok ? *(const f32x4*)(w + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 bb = ok ? *(const f32x4*)(b + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int h = 0; h < NOUT; ++h)
-            wv[h][k] = ok ? *(const f32x4*)(W + (size_t)h * C + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < NOUT; ++h) {
+            const f32x4 wh = ok ? *(const f32x4*)(W + (size_t)h * C + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            a[h][k] = ww * wh;
+            sa[h] += (a[h][k][0] + a[h][k][1]) + (a[h][k][2] + a[h][k][3]);
+            sb[h] += (bb[0] * wh[0] + bb[1] * wh[1]) + (bb[2] * wh[2] + bb[3] * wh[3]);
+        }
     }
-    float hbv[NOUT];
 #pragma unroll
-    for (int h = 0; h < NOUT; ++h) hbv[h] = hb[h];
+    for (int h = 0; h < NOUT; ++h) {
+        sa[h] = row16_sum(sa[h]);
+        sb[h] = row16_sum(sb[h]) + hb[h];
+    }
+    auto load = [&](int grp, f32x4 (&v)[NV]) __attribute__((always_inline)) {
+        const size_t roff = (size_t)min(grp * LRD_ROWS + quarter, M - 1) * C;
 #pragma unroll
-    for (int r = 0; r < LRD_ROWS; ++r) {
-        float s = 0.f;
+        for (int k = 0; k < NV; ++k) {
+            const int j = sub + k * 16;
+            v[k] = j < cv ? *(const f32x4*)(x + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x4 v[NV], vn[NV];
+    load(wave_id, v);
+    for (int grp = wave_id; grp < ngroups; grp += nwaves) {
+        const bool more = grp + nwaves < ngroups;
+        if (more) load(grp + nwaves, vn);
+        float s = 0.f, dot[NOUT];
 #pragma unroll
-        for (int k = 0; k < NV; ++k)
-            if (lane + k * 64 < cv) s += (v[r][k][0] + v[r][k][1]) + (v[r][k][2] + v[r][k][3]);
-        const float mean = wave_sum(s) / (float)C;
+        for (int h = 0; h < NOUT; ++h) dot[h] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {        // lanes beyond the row hold zeros
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+#pragma unroll
+            for (int h = 0; h < NOUT; ++h)
+                dot[h] += (v[k][0] * a[h][k][0] + v[k][1] * a[h][k][1]) + (v[k][2] * a[h][k][2] + v[k][3] * a[h][k][3]);
+        }
+        const float mean = row16_sum(s) / (float)C;
         float q = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k)
-            if (lane + k * 64 < cv) {
+            if (sub + k * 16 < cv) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float dlt = v[r][k][e] - mean;
+                    const float dlt = v[k][e] - mean;
                     q += dlt * dlt;
                 }
             }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-        float acc[NOUT];
-#pragma unroll
-        for (int h = 0; h < NOUT; ++h) acc[h] = 0.f;
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-            if (lane + k * 64 < cv) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[r][k][e] - mean) * rstd * ww[k][e] + bb[k][e];
-#pragma unroll
-                for (int h = 0; h < NOUT; ++h)
-                    acc[h] += (o[0] * wv[h][k][0] + o[1] * wv[h][k][1]) + (o[2] * wv[h][k][2] + o[3] * wv[h][k][3]);
-            }
+        const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)C + eps);
+        const int row = grp * LRD_ROWS + quarter;
 #pragma unroll
         for (int h = 0; h < NOUT; ++h) {
-            const float t = wave_sum(acc[h]);
-            if (lane == 0 && row0 + r < M) out[(size_t)(row0 + r) * NOUT + h] = t + hbv[h];
+            const float d_ = row16_sum(dot[h]);
+            if (sub == 0 && row < M) out[(size_t)row * NOUT + h] = rstd * (d_ - mean * sa[h]) + sb[h];
+        }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = vn[k];
         }
     }
 }
@@ -839,7 +854,10 @@ extern "C" int fs2_layernorm_rowdot(const float* x, const float* w, const float*
                   "fs2_layernorm_rowdot: C=%d nout=%d unsupported", C, nout);
     if (M <= 0) return FS2_OK;
     if (C <= 512 && (nout == 4 || nout == 1)) {        // the model's heads: pitch (4) and energy (1), C = 384
-        const dim3 grid(blocks_for(M, 4 * LRD_ROWS));
+        const long long want = blocks_for(M, 4 * LRD_ROWS);
+        // at most 8 waves per CU walking the row groups with a grid stride (256 / 512 / 768 / 1024 / 2048 workgroups at
+        // 24.7 k rows: 15.8 / 13.5 / 17.1 / 16.0 / 20.6 us for the 4-wide head, 11.6 / 9.9 / 9.6 / 9.5 / 10.7 us for the 1-wide)
+        const dim3 grid((unsigned)(want < 512 ? want : 512));
         if (nout == 4)
             hipLaunchKernelGGL(layernorm_rowdot_kernel<4>, grid, dim3(256), 0, stream, x, w, b, W, hb, out, M, C, eps);
         else
