@@ -432,22 +432,25 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
             // all K fragments of the tile are requested before the first MFMA; left to itself the compiler keeps two
             // reads in flight and exposes the LDS latency once per MFMA pair
             bf16x8 kf[2][KS];
+            // (reads and MFMAs alternate between the two key blocks: two accumulation chains, no back-to-back
+            // dependent MFMAs)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+                for (int kb = 0; kb < 2; ++kb) {
                     // row 32 kb + lo; a power-of-two swizzle depends on lo alone (32 kb is a multiple of its period)
                     const int koff = POW2 ? (kx ^ (ks * 32)) : (lo * ROWB + unswz_k(ks * 2 + hi, kb * 32 + lo) * 16);
                     kf[kb][ks] = *(const bf16x8*)(Ks + kb * 32 * ROWB + koff);
                 }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
-            }
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
         }
         // V^T fragments are requested now: they land under the softmax arithmetic
         bf16x4 vf[DB][8];      // [db][4 kb + 2 j + half]
