@@ -127,22 +127,22 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) s[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int row = nt * 16 + i;
-            const unsigned char* rowp = Ks + row * ROWB;
+        for (int ks = 0; ks < KS; ++ks) {
+            frag_t kf[4];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                frag_t kf;
+            for (int nt = 0; nt < 4; ++nt) {
+                const int row = nt * 16 + i;
+                const unsigned char* rowp = Ks + row * ROWB;
                 if constexpr (sizeof(T) == 2) {
-                    kf = *(const frag_t*)(rowp + (((ks * 4 + g) + rot_k(row)) % NS) * 16);
+                    kf[nt] = *(const frag_t*)(rowp + (((ks * 4 + g) + rot_k(row)) % NS) * 16);
                 } else {
                     const f32x4 v0 = *(const f32x4*)(rowp + (((ks * 8 + 2 * g) + rot_k(row)) % NS) * 16);
                     const f32x4 v1 = *(const f32x4*)(rowp + (((ks * 8 + 2 * g + 1) + rot_k(row)) % NS) * 16);
-                    kf = (frag_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    kf[nt] = (frag_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 }
-#pragma unroll
-                for (int t = 0; t < QT; ++t) s[t][nt] = mma16(kf, qf[t][ks], s[t][nt]);
             }
+#pragma unroll
+            for (int t = 0; t < QT; ++t) mma16_multi<4>(kf, qf[t][ks], s[t]);      // four key tiles: four accumulation chains
         }
 
         // ---- online softmax, per query (lane-local; the 4 lane groups hold different keys) -------
@@ -217,33 +217,37 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
                     pf[t][4 + r] = from_f32<T>(s[t][2 * c + 1][r]);
                 }
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                frag_t vf;
-                if constexpr (sizeof(T) == 2) {
-                    // transposed 4x16 block read: lane 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
-                    const int row0 = (2 * c) * 16 + 4 * g + (i >> 2);
-                    const int row1 = row0 + 16;
-                    const int slot = dt * 2 + ((i & 3) >> 1);
-                    const int sub = (i & 1) * 8;
-                    const unsigned char* p0 = Vs + row0 * ROWB + ((slot + rot_v(row0)) % NS) * 16 + sub;
-                    const unsigned char* p1 = Vs + row1 * ROWB + ((slot + rot_v(row1)) % NS) * 16 + sub;
-                    const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
-                    const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
+            for (int dt0 = 0; dt0 < DT; dt0 += 2) {      // two dv tiles at a time: two accumulation chains per q-tile
+                frag_t vf[2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        vf[r] = lo4[r];
-                        vf[4 + r] = hi4[r];
-                    }
-                } else {
+                for (int u = 0; u < 2; ++u) {
+                    const int dt = dt0 + u;
+                    if constexpr (sizeof(T) == 2) {
+                        // transposed 4x16 block read: lane 4q+p of a 16-lane group supplies row q, cols 4p..4p+3
+                        const int row0 = (2 * c) * 16 + 4 * g + (i >> 2);
+                        const int row1 = row0 + 16;
+                        const int slot = dt * 2 + ((i & 3) >> 1);
+                        const int sub = (i & 1) * 8;
+                        const unsigned char* p0 = Vs + row0 * ROWB + ((slot + rot_v(row0)) % NS) * 16 + sub;
+                        const unsigned char* p1 = Vs + row1 * ROWB + ((slot + rot_v(row1)) % NS) * 16 + sub;
+                        const bf16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p0);
+                        const bf16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p1);
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int row = (2 * c + (jj >> 2)) * 16 + 4 * g + (jj & 3);
-                        const int col = dt * 16 + i;
-                        vf[jj] = *(const T*)(Vs + row * ROWB + (((col >> 2) + rot_v(row)) % NS) * 16 + (col & 3) * 4);
+                        for (int r = 0; r < 4; ++r) {
+                            vf[u][r] = lo4[r];
+                            vf[u][4 + r] = hi4[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int row = (2 * c + (jj >> 2)) * 16 + 4 * g + (jj & 3);
+                            const int col = dt * 16 + i;
+                            vf[u][jj] = *(const T*)(Vs + row * ROWB + (((col >> 2) + rot_v(row)) % NS) * 16 + (col & 3) * 4);
+                        }
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < QT; ++t) o[t][dt] = mma16(vf, pf[t], o[t][dt]);
+                for (int t = 0; t < QT; ++t) mma16_multi<2>(vf, pf[t], &o[t][dt0]);
             }
         }
     }

@@ -42,6 +42,20 @@ __device__ __forceinline__ f32x4 mma16(const f32x8& a, const f32x8& b, f32x4 c) 
     return c;
 }
 
+// N independent accumulators against one B fragment.  fp32: the 8 k-steps of 4 are walked in the outer loop, so that
+// consecutive MFMAs write different accumulators (a single mma16 is a chain of 8 dependent 16x16x4 MFMAs, each waiting
+// for the one before it).
+template <int N> __device__ __forceinline__ void mma16_multi(const f32x8 (&a)[N], const f32x8& b, f32x4* c) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int n = 0; n < N; ++n) c[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[n][j], b[j], c[n], 0, 0, 0);
+}
+template <int N> __device__ __forceinline__ void mma16_multi(const bf16x8 (&a)[N], const bf16x8& b, f32x4* c) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) c[n] = mma16(a[n], b, c[n]);
+}
+
 template <typename T> __device__ __forceinline__ typename Frag<T>::type frag_zero() {
     typename Frag<T>::type z;
 #pragma unroll
