@@ -449,14 +449,20 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             }
             if (ks == 0) mid();
             if constexpr (SPLIT) {
+                // small terms first, then the leading product; one term over all tiles at a time, so that the three
+                // MFMAs of an accumulator are MT * NT instructions apart instead of back to back
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {       // small terms first, then the leading product
-                        acc[mt][nt] = mma16_f16(wl[nt], xh[mt], acc[mt][nt]);
-                        acc[mt][nt] = mma16_f16(wh[nt], xl[mt], acc[mt][nt]);
-                        acc[mt][nt] = mma16_f16(wh[nt], xh[mt], acc[mt][nt]);
-                    }
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16_f16(wl[nt], xh[mt], acc[mt][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16_f16(wh[nt], xl[mt], acc[mt][nt]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16_f16(wh[nt], xh[mt], acc[mt][nt]);
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
