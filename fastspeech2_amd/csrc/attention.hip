@@ -114,7 +114,7 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
     const int ntiles = (len + AT_BK - 1) / AT_BK;
     stage(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();   // tile kt landed (vmcnt(0) + barrier); every wave is done with the other stage
+        vm_wait_barrier<0>();   // tile kt landed (explicit vmcnt(0): not left to the compiler) + barrier; every wave is done with the other stage
         if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* Ks = smem + (kt & 1) * 2 * TILE_BYTES;
         const unsigned char* Vs = Ks + TILE_BYTES;
@@ -549,7 +549,11 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
         stage(1, Vr);
     }
     for (int it = 0; it < trips; ++it) {
-        __syncthreads();   // this trip's tile landed; every wave is done with the previous one
+        // This trip's tile has landed and every wave is done with the previous one.  The wait for the DMA is explicit:
+        // with the transposed reads in inline asm hipcc no longer sees an LDS read that could alias the DMA's target and
+        // emitted `s_waitcnt vmcnt(0)` once, in front of the loop - the tile was read unwaited (caught as run-to-run
+        // differences of the decode loop, tools/determinism_check.py; the 16x16x32 kernel relies on the compiler's wait).
+        vm_wait_barrier<0>();
         const int kt = t0 + it;
         const int st = it & 1;
         if (kt + 1 < t1) {

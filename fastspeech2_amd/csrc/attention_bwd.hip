@@ -172,7 +172,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dq_kernel(AttnBwdArgs 
     };
     stage(0, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
+        vm_wait_barrier<0>();      // the tile's LDS-DMA has landed (explicit vmcnt(0)); every wave is done with the other stage
         if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
         const unsigned char* Ks = smem + (kt & 1) * 2 * TILE;
         const unsigned char* Vs = Ks + TILE;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_dkv_kernel(AttnBwdArgs
     };
     stage(0, 0);
     for (int qt = 0; qt < ntiles; ++qt) {
-        __syncthreads();
+        vm_wait_barrier<0>();      // the tile's LDS-DMA has landed (explicit vmcnt(0)); every wave is done with the other stage
         if (qt + 1 < ntiles) stage(qt + 1, (qt + 1) & 1);
         const unsigned char* Qs = smem + (qt & 1) * STAGE;
         const unsigned char* Ds = Qs + TILE;

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             stage_x(chunk_start, 0);
             stage_w(tap_start, chunk_start, 0);
         }
-        __syncthreads();
+        if constexpr (DMA) vm_wait_barrier<0>(); else __syncthreads();
 
         int xcur = 0, wcur = 0;
         int tap = tap_start, chunk = chunk_start, tcount = 0;
@@ -512,10 +512,12 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
                 if (has_next) stage_w(ntap, nchunk, wcur ^ 1);
                 if (next_x) stage_x(nchunk, xcur ^ 1);
             }
-            __syncthreads();   // also drains the LDS-DMA (vmcnt(0)) issued at the top of this step
+            // end of the step: the LDS-DMA issued at its top has landed (the vmcnt(0) is written out, not left to the
+            // compiler's alias analysis of LDS-DMA against LDS reads) and every wave is done with the stage
+            if constexpr (DMA) vm_wait_barrier<0>(); else __syncthreads();
             if (DMA && !XDB && next_x) {   // single X image: refill it once per channel chunk, between two barriers
                 stage_x(nchunk, 0);
-                __syncthreads();
+                vm_wait_barrier<0>();
             }
             wcur ^= 1;
             if (XDB && next_x) xcur ^= 1;
