@@ -316,20 +316,28 @@ __device__ __forceinline__ void lds_tr_wait(bf16x4 (&v)[8]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
+__device__ __forceinline__ void lds_tr_wait(bf16x4 (&v)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
 
-template <int DK, bool DROP, int G>
-__global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(AttnArgs a) {
+// NW = 2, KB = 1 (128 threads, 64 queries per workgroup, 32-key tiles, 32 KB of LDS at dk = 128: four workgroups per
+// CU): the same tile code on half the keys per trip, i.e. twice the work items of half the size; launch_attention uses
+// it for short utterances (measurements there and in DESIGN.md section 4.2).
+template <int DK, bool DROP, int G, int NW = 4, int KB = 2>
+__global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArgs a) {
     typedef bf16_t T;
+    constexpr int BKT = 32 * KB;                     // keys per tile
     constexpr int ROWB = DK * 2;                     // bytes per K/V row
     constexpr int NS = ROWB / 16;                    // 16-byte slots per row
-    constexpr int TILE_BYTES = AT_BK * ROWB;
+    constexpr int TILE_BYTES = BKT * ROWB;
     constexpr int PIECES = TILE_BYTES / 1024;        // 1-KiB DMA pieces per tile
     constexpr int KS = DK / 16;                      // k-steps of Q . K over dk
     constexpr int DB = DK / 32;                      // 32-wide dv blocks
     constexpr int RSH = ROWB == 256 ? 0 : (ROWB == 128 ? 1 : (ROWB == 64 ? 2 : 0));
     constexpr bool POW2 = (NS & (NS - 1)) == 0;
-    constexpr int BQ = 128;                          // queries per workgroup
-    static_assert(PIECES % 4 == 0, "one DMA piece per wave and step");
+    constexpr int BQ = 32 * NW;                      // queries per workgroup
+    static_assert(PIECES % NW == 0, "one DMA piece per wave and step");
+    static_assert(G == 1 || (NW == 4 && KB == 2), "two key groups: four waves per group, 64-key tiles");
     static_assert(G == 1 || 8 * TILE_BYTES >= 4 * 64 * (16 * DB + 2) * 4, "the merge buffer reuses the K/V rings");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -343,13 +351,13 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave8 & 3, grp = wave8 >> 2;    // wave within its key group, key group
+    const int wave = G == 1 ? wave8 : (wave8 & 3), grp = G == 1 ? 0 : (wave8 >> 2);    // wave within its key group, key group
     const int hi = lane >> 5, lo = lane & 31;
     const T* __restrict__ base = (const T*)a.qkv + (size_t)r0 * a.ld;
     const int qcol = h * DK, kcol = a.d + h * DK, vcol = 2 * a.d + h * DK;
 
     // key tiles [t0, t1) of this group; every group runs `trips` iterations (barriers are workgroup-wide)
-    const int ntiles = (len + AT_BK - 1) / AT_BK;
+    const int ntiles = (len + BKT - 1) / BKT;
     const int trips = (ntiles + G - 1) / G;
     const int t0 = grp * trips;
     const int t1 = (t0 + trips) < ntiles ? (t0 + trips) : ntiles;
@@ -367,35 +375,38 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
         return POW2 ? (slot ^ ((row >> RSH) & (NS - 1))) : (slot + row) % NS;
     };
 
-    // DMA: one 1-KiB piece per wave and step pp: piece p = wave + 4 pp covers rows (p * 1024 + 16 lane) / ROWB.  The
+    // DMA: one 1-KiB piece per wave and step pp: piece p = wave + NW pp covers rows (p * 1024 + 16 lane) / ROWB.  The
     // source is a 32-bit byte offset from the utterance's first row (scalar base + vector offset), carried from tile to
-    // tile: src[v][pp] (v = 0: K, 1: V) advances by 64 rows per call; rows beyond the utterance (last tile only; masked
+    // tile: src[v][pp] (v = 0: K, 1: V) advances by BKT rows per call; rows beyond the utterance (last tile only; masked
     // with -inf later) read its last row instead: min() with the same piece's offset in that row.
-    constexpr int PP = PIECES / 4;
-    constexpr int LC = POW2 ? 1 : PP;               // power-of-two rows: piece pp is piece 0 moved down 4096 / ROWB rows
+    constexpr int PP = PIECES / NW;
+    // power-of-two rows: piece pp is piece 0 moved down NW * 1024 / ROWB rows, with the same swizzle when that is a
+    // multiple of the swizzles' 16-row period (not for two waves at dk = 128: 8 rows)
+    constexpr bool ONE = POW2 && ((NW * 1024 / ROWB) % 16 == 0);
+    constexpr int LC = ONE ? 1 : PP;
     const unsigned ldb = (unsigned)a.ld * 2u;
-    const unsigned tile_step = AT_BK * ldb;
-    const unsigned piece_step = (4096 / ROWB) * ldb;
+    const unsigned tile_step = BKT * ldb;
+    const unsigned piece_step = (NW * 1024 / ROWB) * ldb;
     unsigned src[2][LC], src_last[2][LC];
 #pragma unroll
     for (int pp = 0; pp < LC; ++pp) {
-        const unsigned off = (unsigned)((wave + 4 * pp) * 1024 + lane * 16);
+        const unsigned off = (unsigned)((wave + NW * pp) * 1024 + lane * 16);
         const int row = (int)(off / (unsigned)ROWB);
         const int slot = (int)(off % (unsigned)ROWB) >> 4;
         const unsigned ck = (unsigned)((kcol + swz_k(slot, row) * 8) * 2), cv = (unsigned)((vcol + swz_v(slot, row) * 8) * 2);
-        src[0][pp] = (unsigned)(t0 * AT_BK + row) * ldb + ck;
-        src[1][pp] = (unsigned)(t0 * AT_BK + row) * ldb + cv;
+        src[0][pp] = (unsigned)(t0 * BKT + row) * ldb + ck;
+        src[1][pp] = (unsigned)(t0 * BKT + row) * ldb + cv;
         src_last[0][pp] = (unsigned)(len - 1) * ldb + ck;
         src_last[1][pp] = (unsigned)(len - 1) * ldb + cv;
     }
     auto stage = [&](int v, unsigned char* dst) __attribute__((always_inline)) {      // next tile of stream v
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
-            const unsigned cur = POW2 ? src[v][0] + pp * piece_step : src[v][POW2 ? 0 : pp];
-            const unsigned last = src_last[v][POW2 ? 0 : pp];
+            const unsigned cur = ONE ? src[v][0] + pp * piece_step : src[v][ONE ? 0 : pp];
+            const unsigned last = src_last[v][ONE ? 0 : pp];
             const unsigned so = cur < last ? cur : last;
             __builtin_amdgcn_global_load_lds((at_gbl_void*)((const unsigned char*)base + so),
-                                             (at_lds_void*)(dst + (wave + 4 * pp) * 1024), 16, 0, 0);
+                                             (at_lds_void*)(dst + (wave + NW * pp) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int pp = 0; pp < LC; ++pp) src[v][pp] += tile_step;
@@ -428,36 +439,36 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
 
     // one key tile: s = K . Q^T; online softmax; O^T += V^T . P^T
     auto tile = [&](int kt, const unsigned char* Ks, const unsigned char* Vs) __attribute__((always_inline)) {
-        const int k0 = kt * AT_BK;
-        f32x16 s[2];      // s[kb][r] = score(key 32 kb + 8 (r / 4) + 4 hi + r % 4, query lo)
+        const int k0 = kt * BKT;
+        f32x16 s[KB];     // s[kb][r] = score(key 32 kb + 8 (r / 4) + 4 hi + r % 4, query lo)
         {
             int kx = kx0;
             asm volatile("" : "+v"(kx));      // the per-step addresses are rebuilt per tile, not carried through the loop
             // all K fragments of the tile are requested before the first MFMA; left to itself the compiler keeps two
             // reads in flight and exposes the LDS latency once per MFMA pair
-            bf16x8 kf[2][KS];
+            bf16x8 kf[KB][KS];
             // (reads and MFMAs alternate between the two key blocks: two accumulation chains, no back-to-back
             // dependent MFMAs)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < KB; ++kb) {
                     // row 32 kb + lo; a power-of-two swizzle depends on lo alone (32 kb is a multiple of its period)
                     const int koff = POW2 ? (kx ^ (ks * 32)) : (lo * ROWB + unswz_k(ks * 2 + hi, kb * 32 + lo) * 16);
                     kf[kb][ks] = *(const bf16x8*)(Ks + kb * 32 * ROWB + koff);
                 }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
+                for (int kb = 0; kb < KB; ++kb) s[kb] = mma32(kf[kb][ks], qf[ks], s[kb]);
         }
         // V^T fragments are requested now: they land under the softmax arithmetic
-        bf16x4 vf[DB][8];      // [db][4 kb + 2 j + half]
+        bf16x4 vf[DB][4 * KB];      // [db][4 kb + 2 j + half]
         {
             int vx = vx0;
             asm volatile("" : "+v"(vx));
@@ -469,22 +480,24 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
                 vf[db][1] = lds_read_tr<8 * ROWB>(vb);
                 vf[db][2] = lds_read_tr<16 * ROWB>(vb);
                 vf[db][3] = lds_read_tr<24 * ROWB>(vb);
-                vf[db][4] = lds_read_tr<32 * ROWB>(vb);
-                vf[db][5] = lds_read_tr<40 * ROWB>(vb);
-                vf[db][6] = lds_read_tr<48 * ROWB>(vb);
-                vf[db][7] = lds_read_tr<56 * ROWB>(vb);
+                if constexpr (KB == 2) {
+                    vf[db][4] = lds_read_tr<32 * ROWB>(vb);
+                    vf[db][5] = lds_read_tr<40 * ROWB>(vb);
+                    vf[db][6] = lds_read_tr<48 * ROWB>(vb);
+                    vf[db][7] = lds_read_tr<56 * ROWB>(vb);
+                }
             }
         }
-        if ((k0 + AT_BK) > len) {     // last tile only: keys beyond the utterance get -inf (exp2 -> exactly 0)
+        if ((k0 + BKT) > len) {     // last tile only: keys beyond the utterance get -inf (exp2 -> exactly 0)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if ((k0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) >= len) s[kb][r] = -INFINITY;
         }
         float m_loc = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m_loc = fmaxf(m_loc, s[kb][r]);
         m_loc = halves_max(m_loc) * a.scale_log2e;                  // scale > 0: the maximum commutes with it
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], a.scale_log2e, -m_new));
@@ -512,14 +525,14 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
             dh.stream += (uint32_t)h;
             const uint32_t qg = (uint32_t)(r0 + qrow);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     s[kb][r] *= drop_mul(dh, qg, (uint32_t)(k0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)));
         }
-        bf16x8 pf[2][2];
+        bf16x8 pf[KB][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -528,7 +541,7 @@ __global__ __launch_bounds__(AT_THREADS * G, 2 / G) void attention32_kernel(Attn
         for (int db = 0; db < DB; ++db) {
             lds_tr_wait(vf[db]);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     bf16x8 v8;
@@ -653,16 +666,27 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
             // config 4 B = 1, 86 -> 71 us; 264 or 448 workgroups are 10 % faster with one group, two per CU)
             const long items = (long)B * H * ((max_len + 127) / 128);
             const bool two = groups ? groups == 2 : (max_len > 4 * AT_BK && items <= 256);
-            static unsigned long long ok[4] = {0, 0, 0, 0};
+            // 64-query workgroups on 32-key tiles for short utterances (phone level: <= 256 keys, i.e. one or two
+            // 128-query items per pair): twice the workgroups of half the size, 9.0 -> 7.7 us at 32 x ~120 phones.  At
+            // the frame level it loses (config 2: 43.3 vs 39.8 us, uniform 64 x 1024: 644 vs 795-810 TFLOP/s: both forms
+            // have every workgroup resident from the start, and 32-key trips pay the per-trip costs twice).
+            // FS2_ATTN_Q64 = 0 / 1 forces (A/B runs).
+            static const int q64_env = getenv("FS2_ATTN_Q64") ? atoi(getenv("FS2_ATTN_Q64")) : -1;
+            const bool q64 = !two && (q64_env >= 0 ? q64_env != 0 : max_len <= 4 * AT_BK);
+            static unsigned long long ok[6] = {0, 0, 0, 0, 0, 0};
             const void* k;
             if (aa.drop.thresh)
-                k = two ? (const void*)attention32_kernel<DK, true, 2> : (const void*)attention32_kernel<DK, true, 1>;
+                k = q64 ? (const void*)attention32_kernel<DK, true, 1, 2, 1>
+                        : (two ? (const void*)attention32_kernel<DK, true, 2> : (const void*)attention32_kernel<DK, true, 1>);
             else
-                k = two ? (const void*)attention32_kernel<DK, false, 2> : (const void*)attention32_kernel<DK, false, 1>;
-            const int lds32 = (two ? 2 : 1) * lds;
-            fs2_allow_lds(k, lds32, &ok[(two ? 2 : 0) + (aa.drop.thresh ? 1 : 0)]);
+                k = q64 ? (const void*)attention32_kernel<DK, false, 1, 2, 1>
+                        : (two ? (const void*)attention32_kernel<DK, false, 2> : (const void*)attention32_kernel<DK, false, 1>);
+            const int lds32 = q64 ? lds / 2 : (two ? 2 : 1) * lds;
+            const int threads = q64 ? 128 : AT_THREADS * (two ? 2 : 1);
+            const dim3 grid32 = q64 ? fs2_pair_order_grid(aa.order, (max_len + 63) / 64, H, B, xcd_on != 0) : grid;
+            fs2_allow_lds(k, lds32, &ok[(q64 ? 4 : (two ? 2 : 0)) + (aa.drop.thresh ? 1 : 0)]);
             void* params[] = {&aa};
-            if (hipLaunchKernel(k, grid, dim3(AT_THREADS * (two ? 2 : 1)), params, lds32, stream) != hipSuccess) {
+            if (hipLaunchKernel(k, grid32, dim3(threads), params, lds32, stream) != hipSuccess) {
                 fs2_set_error("fs2_attention: launch failed: %s", hipGetErrorString(hipGetLastError()));
                 return FS2_ERR_HIP;
             }

@@ -375,6 +375,7 @@ def test_length_regulator_bit_exact(control):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("h,dk,lens", [(2, 32, [1, 70, 5]), (2, 64, [129, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 64]),
+                                       (2, 128, [120, 64, 33, 256]),      # <= 256 keys: the 64-query / 32-key-tile form at dk 128
                                        (2, 64, [130, 64, 257, 1, 90]),    # 10 pairs: XCD-aware order with a padded grid
                                        (2, 128, [130, 4165, 3000])])      # BASELINE config 4: ~4000-frame decoder rows
 def test_attention(dtype, h, dk, lens):

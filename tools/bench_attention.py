@@ -13,7 +13,11 @@ d = h * dk
 rng = np.random.Generator(np.random.PCG64(0))
 cases = [("config 2 decoder", np.clip(np.rint(rng.normal(800, 100, 32)), 400, 1200).astype(int).tolist()),
          ("config 2 encoder", np.clip(np.rint(rng.normal(120, 15, 32)), 60, 180).astype(int).tolist()),
-         ("config 4 B=1", [4165]), ("config 4 B=4", [4165, 4100, 3900, 4000])]
+         ("config 4 B=1", [4165]), ("config 4 B=4", [4165, 4100, 3900, 4000]),
+         ("uniform 64 x 1024", [1024] * 64)]      # no imbalance: the tile code's own rate
+order = os.environ.get("FS2_BENCH_SORT", "")      # "desc" / "asc": utterances sorted by length (decode() hands over descending)
+if order:
+    cases = [(n, sorted(l, reverse=order == "desc")) for n, l in cases]
 for dtype in (sys.argv[1:] or ["bf16", "fp32"]):
     code, tdt = hip.DTYPE_CODE[dtype], hip.TORCH_DTYPE[hip.DTYPE_CODE[dtype]]
     for name, lens in cases:
