@@ -277,6 +277,31 @@ def test_layernorm(C):
     assert torch.allclose(oc.cpu(), b.expand(2, C), atol=1e-6)
 
 
+@pytest.mark.parametrize("C,nparts,with_x,pre_ln", [(256, 3, True, False), (256, 1, False, False), (384, 0, True, False),
+                                                    (256, 2, True, True), (512, 1, True, False), (64, 1, True, False)])
+def test_add_layernorm_partials_many_rows(C, nparts, with_x, pre_ln):
+    # residual + split-K partials + LayerNorm over many rows (M % 4 != 0: partly filled last workgroup), bf16 and fp32 copies
+    # against fp64; the bf16 and the fp32 launch must agree on the fp32 output and on the pre-LN sum.
+    g = torch.Generator().manual_seed(C + nparts)
+    M = 1030 + 1
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(DEV)
+    parts = torch.randn(max(nparts, 1), M, C, generator=g).to(DEV)
+    w, b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    o32, o32_ref = torch.full((M, C), float("nan"), device=DEV), torch.empty((M, C), device=DEV)
+    obf = torch.empty((M, C), device=DEV, dtype=torch.bfloat16)
+    ssum, ssum_ref = torch.empty((M, C), device=DEV), torch.empty((M, C), device=DEV)
+    args = (ptr(x) if with_x else None, ptr(parts) if nparts else None, nparts, M * C, ptr(w), ptr(b))
+    call("fs2_add_layernorm", *args, ptr(ssum) if pre_ln else None, ptr(o32), ptr(obf), M, C, 1e-12, hip.BF16, stream())
+    call("fs2_add_layernorm", *args, ptr(ssum_ref) if pre_ln else None, ptr(o32_ref), None, M, C, 1e-12, hip.F32, stream())
+    y = (x.double() if with_x else 0) + (parts[:nparts].double().sum(0) if nparts else 0)
+    exp = F.layer_norm(y, (C,), w.double(), b.double(), 1e-12)
+    assert (o32.double() - exp).abs().max().item() <= 2e-5 * max(1.0, exp.abs().max().item())
+    assert (o32 - o32_ref).abs().max().item() <= 1e-5 * max(1.0, exp.abs().max().item())
+    assert (obf.double() - exp).abs().max().item() <= 2 ** -8 * max(1.0, exp.abs().max().item())
+    if pre_ln:
+        assert torch.equal(ssum, ssum_ref)           # the sum itself is taken in the same order
+
+
 @pytest.mark.parametrize("nout,C", [(1, 256), (4, 384), (1, 64)])
 def test_rowdot(nout, C):
     g = torch.Generator().manual_seed(nout + C)
