@@ -41,7 +41,9 @@ typedef const __attribute__((address_space(1))) void at_gbl_void;
 // 8-row transposed reads of V spread over all bank groups.  The tiles are filled by LDS-DMA
 // (global_load_lds_dwordx4): the LDS side is lane-linear, the rotation is applied to the per-lane
 // SOURCE address.  Two stages: tile t+1 is in flight while tile t is consumed (one barrier per tile).
-template <typename T, int DK, int QT>
+// OT: element type of ctx: T, or f16pair_t over T = float (split-fp16 storage: the context of the f16x3 phone-level half
+// goes straight to the output projection's GEMM operand form, common.h store4<f16pair_t>).
+template <typename T, int DK, int QT, typename OT = T>
 __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
     typedef typename Frag<T>::type frag_t;
     constexpr int ROWB = DK * (int)sizeof(T);        // bytes per K/V row
@@ -259,13 +261,18 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
         const float inv = 1.0f / l;
         if (a.lse && g == 0 && qrow[t] < len) a.lse[(size_t)h * a.M + r0 + qrow[t]] = m_run[t] + __log2f(l);
         if (qrow[t] < len) {
-            T* dst = (T*)a.ctx + (size_t)(r0 + qrow[t]) * a.ldo + h * DK;
+            OT* dst = (OT*)a.ctx + (size_t)(r0 + qrow[t]) * a.ldo + h * DK;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 f32x4 v = o[t][dt];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= inv;
-                store4<T>(dst + dt * 16 + 4 * g, v);
+                for (int r = 0; r < 4; ++r) {
+                    v[r] *= inv;
+                    // a split store takes hi / lo of the ROUNDED fp32 product, as fs2_cast of an fp32 context would:
+                    // the product must not be contracted into the low half's subtraction
+                    if constexpr (sizeof(OT) != sizeof(T) || !__is_same(OT, T)) asm volatile("" : "+v"(v[r]));
+                }
+                store4<OT>(dst + dt * 16 + 4 * g, v);
             }
         }
     }
@@ -649,12 +656,12 @@ __global__ __launch_bounds__(256) void attention_dump_kernel(const T* __restrict
     for (int k = lane; k < len; k += 64) out[k] = out[k] / sum;
 }
 
-template <typename T, int DK>
+template <typename T, int DK, typename OT = T>
 static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStream_t stream) {
     constexpr int QT = sizeof(T) == 2 ? 2 : 1;     // 32 (bf16) / 16 (f32) queries per wave
     constexpr int lds = 2 * 2 * AT_BK * DK * (int)sizeof(T);
     static unsigned long long lds_ok = 0;
-    fs2_allow_lds((const void*)attention_kernel<T, DK, QT>, lds, &lds_ok);
+    fs2_allow_lds((const void*)attention_kernel<T, DK, QT, OT>, lds, &lds_ok);
     static const int xcd_on = getenv("FS2_ATTN_XCD") ? atoi(getenv("FS2_ATTN_XCD")) : 1;   // 0: plain grid (A/B runs)
     AttnArgs aa = a;
     const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 64 * QT - 1) / (64 * QT), H, B, xcd_on != 0);
@@ -693,7 +700,7 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
             return FS2_OK;
         }
     }
-    hipLaunchKernelGGL((attention_kernel<T, DK, QT>), grid, dim3(AT_THREADS), lds, stream, aa);
+    hipLaunchKernelGGL((attention_kernel<T, DK, QT, OT>), grid, dim3(AT_THREADS), lds, stream, aa);
     FS2_CHECK_LAUNCH("fs2_attention");
     return FS2_OK;
 }
@@ -705,11 +712,14 @@ using namespace fs2;
 static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
                            int dk, int ld, int ldo, int dtype, Dropout drop, hipStream_t stream) {
     FS2_CHECK_ARG(qkv && ctx && cu && B > 0 && n_heads > 0, "fs2_attention: bad args");
-    FS2_CHECK_ARG(dtype == 0 || dtype == 1, "fs2_attention: dtype=%d", dtype);
+    FS2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2, "fs2_attention: dtype=%d", dtype);
+    FS2_CHECK_ARG(dtype != 2 || (!lse && !drop.thresh && ldo % 32 == 0 && ((uintptr_t)ctx & 127) == 0),
+                  "fs2_attention(f16x3): the split-fp16 context needs ldo=%d in multiples of 32 and 128-byte alignment; "
+                  "inference only", ldo);
     FS2_CHECK_ARG(dk == 32 || dk == 64 || dk == 96 || dk == 128, "fs2_attention: head dim %d unsupported (32/64/96/128)",
                   dk);
     const int d = n_heads * dk;
-    const int epv = dtype == 0 ? 4 : 8;
+    const int epv = dtype == 1 ? 8 : 4;
     FS2_CHECK_ARG(ld >= 3 * d && ldo >= d && ld % epv == 0 && ldo % 4 == 0, "fs2_attention: bad leading dims");
     FS2_CHECK_ARG(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ctx & 15) == 0, "fs2_attention: unaligned pointers");
     if (max_len <= 0) return FS2_OK;
@@ -717,7 +727,12 @@ static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu
     a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M; a.drop = drop;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dk);
 #define FS2_ATT(TT, DKK) return launch_attention<TT, DKK>(a, B, n_heads, max_len, stream)
-    if (dtype == 0) {
+    if (dtype == 2) {          // fp32 q | k | v, context in split-fp16 storage
+        if (dk == 32) return launch_attention<float, 32, f16pair_t>(a, B, n_heads, max_len, stream);
+        if (dk == 64) return launch_attention<float, 64, f16pair_t>(a, B, n_heads, max_len, stream);
+        if (dk == 96) return launch_attention<float, 96, f16pair_t>(a, B, n_heads, max_len, stream);
+        return launch_attention<float, 128, f16pair_t>(a, B, n_heads, max_len, stream);
+    } else if (dtype == 0) {
         if (dk == 32) FS2_ATT(float, 32);
         if (dk == 64) FS2_ATT(float, 64);
         if (dk == 96) FS2_ATT(float, 96);

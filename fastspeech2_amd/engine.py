@@ -296,15 +296,12 @@ class Engine:
             qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv", out_f32=split)
             if attn_dump is not None:
                 attn_dump.append(self._dump_attention(qkv, lens, ac))
-            ctx = self._empty((M, d), ac)
+            ctx = self._empty((M, d), code)       # f16x3: written in split-fp16 storage by the fp32 attention kernel
             prof = self.profile is not None and lens is not None
             with self._timed("attention:" + ("fp32" if ac == F32 else "bf16") if prof else None, "flop",
                              4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
-                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, ac,
+                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, code,
                      stream())
-            if split:
-                ctx32, ctx = ctx, self._empty((M, d), code)
-                call("fs2_cast", ptr(ctx32), ptr(ctx), M * d, code, stream())
             if st.concat_after:
                 att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
                 pend = self._empty((2, M, d), dtype=torch.float32)

@@ -111,6 +111,8 @@ int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype);
 
 /* Fused varlen multi-head self-attention (scores, softmax, P.V) over packed qkv [M, ld] T laid out
  * q | k | v with each part [n_heads][dk]; ctx [M, ldo] T.  dk in {32, 64, 96, 128}.
+ * dtype 2 (FS2_F16X3): fp32 q | k | v and fp32 arithmetic, ctx written in split-fp16 storage (the operand form of
+ * fs2_conv_gemm_f16x3, as fs2_cast would convert it; ldo % 32 == 0, ctx 128-byte aligned).
  * Replaces MultiHeadedAttention.forward between the projections (network/encoder.py:73-88). */
 int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
                   int ldo, int dtype, hipStream_t stream);

@@ -398,6 +398,20 @@ def test_length_regulator_bit_exact(control):
     assert seg.cpu().tolist() == [[cf[b], cf[b + 1]] for b, L in enumerate(exp_olens) for _ in range(L)]
 
 
+@pytest.mark.parametrize("h,dk,lens", [(2, 128, [120, 64, 33]), (4, 32, [70, 1, 130])])
+def test_attention_split_fp16_context_equals_cast(h, dk, lens):
+    # dtype F16X3: fp32 q | k | v, the context written in split-fp16 storage = fs2_attention (fp32) followed by fs2_cast
+    g = torch.Generator().manual_seed(dk)
+    d, M = h * dk, sum(lens)
+    qkv = torch.randn(M, 3 * d, generator=g).to(DEV)
+    cu_d = torch.from_numpy(_cu(lens)).to(DEV)
+    ctx32, want, got = (torch.empty((M, d), device=DEV) for _ in range(3))
+    call("fs2_attention", ptr(qkv), ptr(ctx32), ptr(cu_d), len(lens), max(lens), h, dk, 3 * d, d, hip.F32, stream())
+    call("fs2_cast", ptr(ctx32), ptr(want), M * d, hip.F16X3, stream())
+    call("fs2_attention", ptr(qkv), ptr(got), ptr(cu_d), len(lens), max(lens), h, dk, 3 * d, d, hip.F16X3, stream())
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("h,dk,lens", [(2, 32, [1, 70, 5]), (2, 64, [129, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 64]),
                                        (2, 128, [120, 64, 33, 256]),      # <= 256 keys: the 64-query / 32-key-tile form at dk 128
