@@ -1,0 +1,65 @@
+"""Run-to-run determinism at BASELINE sizes.  No kernel here uses atomics and every reduction has a fixed order, so a
+repeat of the same launches must give the same bits; a difference is a race (an LDS tile read before its LDS-DMA has
+landed, a stream ordered wrongly), not arithmetic.  This is how the unwaited tile read of attention32_kernel showed
+(tools/determinism_check.py is the longer, 256-utterance form of the inference half)."""
+import numpy as np
+import pytest
+import torch
+
+from fastspeech2_amd import synth
+from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench_model():
+    kw = dict(synth.BASELINE_OVERRIDES)
+    model = FeedForwardTransformer(80, 80, use_scaled_pos_enc=True, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.bench_state_dict().items()})
+    return model.eval().cuda()
+
+
+@pytest.mark.parametrize("precision,encoder", [("bf16", "f16x3"), ("bf16", None), ("fp32", None)])
+def test_inference_repeats_are_bit_identical(precision, encoder):
+    """BASELINE config 2 (32 utterances, ~25 k frames) through the throughput loop (side-stream phone-level halves,
+    three frame-level streams): 4 batches x 3 repeats, every output tensor equal bit for bit."""
+    model = _bench_model().set_precision(precision, encoder)
+    eng = model.engine()
+    batches = []
+    for k in range(4):
+        xs = synth.synth_utterances(32, k)
+        batches.append((torch.from_numpy(np.concatenate(xs)).cuda(), [len(x) for x in xs]))
+
+    def run():
+        outs = []
+        for o in eng.forward_pipelined(batches, frame_streams=3, phone_group=2):
+            o["ready"].synchronize()
+            outs.append({k: o[k].clone() for k in ("mel", "durations", "log_durations", "pitch", "energy", "lr_index")})
+        return outs
+
+    ref = run()
+    for rep in range(2):
+        for a, b in zip(ref, run()):
+            for k in a:
+                assert torch.equal(a[k], b[k]), (rep, k)
+
+
+def test_training_step_repeats_are_bit_identical():
+    """BASELINE config 5 (B = 32, 4+4 blocks, d = 256, conv k = 9), bf16, dropout off: loss and all gradients of two
+    runs of the same step, bit for bit (every gradient has one writer and a fixed summation order)."""
+    z, meta = helpers.load_golden(helpers.BIG_TRAIN_CASES[0])
+    batch = [torch.from_numpy(a) for a in helpers.train_inputs(meta["cfg"], meta["seed"], **meta["inputs"])]
+    from tests.test_gpu_train import _model
+    runs = []
+    for _ in range(2):
+        model = _model(meta, "bf16")
+        model.dropout_enabled = False
+        loss = model(*batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        del model
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
