@@ -20,6 +20,11 @@ constexpr int LNB_ROWS = FS2_LNB_ROWS;   // rows per workgroup (4 waves x LNB_RO
 // Per-workgroup partial sums of d gamma = sum g * xh and d beta = sum g go to wb_part[blk][2][C].
 // NV = float4 per lane (C <= 256 NV); the dγ/dβ staging in LDS is sized to C (dynamic: 8 C floats), so that the
 // kernel's workgroups fit beside the 100 KB conv_wgrad workgroup that shares the CU during a training step.
+// (A form that took a wave's rows four at a time — 16 loads in flight per lane, interleaved reductions, 137 VGPRs / 99
+// SGPRs with SGPR spills — was 20-30 % faster beside conv_wgrad and is NOT kept: about once in 100-200 launches, and only
+// while another kernel shared the CUs, single rows of its output came out wrong (tools/lnb_race.py reproduces it at the
+// kernel level: always the second row of a group; this one-row form: 0 in 400).  No cause was found in the source or
+// the ISA; tests/test_zy_determinism.py and tools/train_determinism_check.py are what caught it.)
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ parts, int nparts,

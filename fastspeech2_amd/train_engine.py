@@ -85,6 +85,9 @@ class _PackGroup:
         call("fs2_pack_weights", ptr(self.table), ptr(self.start), self.n, self.blocks, code, stream())
 
 
+_HOLD = [] if os.environ.get("FS2_TRAIN_HOLD", "0") == "1" else None
+
+
 class TrainEngine:
     SITE_ENC_POS, SITE_DEC_POS = (2 << 16) + 1, (2 << 16) + 2
     SITE_PITCH_EMB, SITE_ENERGY_EMB = (2 << 16) + 3, (2 << 16) + 4
@@ -131,9 +134,10 @@ class TrainEngine:
         self.grad_ready: Optional[Callable[[int], None]] = None   # called with the index of a finished bucket
         self.grad_finish: Optional[Callable[[], None]] = None     # called when every bucket has been announced
         self.profile = None
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev)     # None: weight gradients on the main stream
+        # None (FS2_TRAIN_SIDE_STREAM=0): weight gradients and weight packing on the main stream (debugging aid)
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) if os.environ.get("FS2_TRAIN_SIDE_STREAM", "1") != "0" else None
         self._pack_groups = None
-        self._side_raw = self.wgrad_stream.cuda_stream           # raw hipStream_t of the side stream
+        self._side_raw = self.wgrad_stream.cuda_stream if self.wgrad_stream is not None else None   # raw hipStream_t of the side stream
         self._ws_cache = {}
         self._wgrad_pending = False
 
@@ -268,7 +272,10 @@ class TrainEngine:
         return self._pe
 
     def _empty(self, shape, dtype=None):
-        return torch.empty(shape, device=self.dev, dtype=dtype or self.tdt)
+        t = torch.empty(shape, device=self.dev, dtype=dtype or self.tdt)
+        if _HOLD is not None:             # FS2_TRAIN_HOLD=1 (debugging aid): no block is handed out twice
+            _HOLD.append(t)
+        return t
 
     def _ws(self, nbytes, raw_stream=None):
         """Kernel scratch (split partials, per-workgroup sums).  One buffer per stream, grown on demand: the kernels
@@ -390,6 +397,8 @@ class TrainEngine:
         dy.record_stream(side)
         x.record_stream(side)
         self._wgrad_pending = True
+        if os.environ.get("FS2_TRAIN_WGRAD_SYNC", "0") == "1":      # debugging aid: the streams never run side by side
+            self._join_wgrad()
 
     def producer_streams(self):
         """streams whose enqueued work writes the gradient buffer (a bucket consumer must order itself after both)"""

@@ -1,7 +1,9 @@
 """Run-to-run determinism at BASELINE sizes.  No kernel here uses atomics and every reduction has a fixed order, so a
 repeat of the same launches must give the same bits; a difference is a race (an LDS tile read before its LDS-DMA has
 landed, a stream ordered wrongly), not arithmetic.  This is how the unwaited tile read of attention32_kernel showed
-(tools/determinism_check.py is the longer, 256-utterance form of the inference half)."""
+(tools/determinism_check.py is the longer, 256-utterance form of the inference half;
+tools/train_determinism_check.py the training half with the names of the tensors that differ).  Collected late on
+purpose (pytest -x): a timing-dependent failure here must not hide the parity tests."""
 import numpy as np
 import pytest
 import torch
