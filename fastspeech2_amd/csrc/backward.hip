@@ -10,7 +10,7 @@ namespace fs2 {
 
 constexpr int LNB_MAXV = 4;          // float4 per lane at most -> C <= 1024
 #ifndef FS2_LNB_ROWS
-#define FS2_LNB_ROWS 32
+#define FS2_LNB_ROWS 16      // training step, A/B/A/B in one gpurun call: 64 rows 8.75 ms, 32 rows 8.23-8.26, 16 rows 8.09-8.10, 8 rows 8.09
 #endif
 constexpr int LNB_ROWS = FS2_LNB_ROWS;   // rows per workgroup (4 waves x LNB_ROWS / 4 rows)
 
