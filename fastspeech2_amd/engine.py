@@ -164,8 +164,11 @@ class Engine:
             raise NotImplementedError("head dim %d: the attention kernel supports 32/64/96/128" % self.dk)
         if cfg["positionwise_layer_type"] not in ("linear", "conv1d"):
             raise NotImplementedError("not implemented")          # network/encoder.py:232
-        if cfg["reduction_factor"] != 1:
-            raise NotImplementedError("reduction_factor != 1")
+        # reduction_factor r > 1 (network/fastspeech2.py:219): feat_out gives r mel frames per decoder frame; inference
+        # only (the reference's training masks for r > 1 are not self-consistent)
+        self.r = int(cfg["reduction_factor"])
+        if self.r < 1:
+            raise ValueError("reduction_factor must be >= 1")
         sd, dev = state_dict, self.dev
         self.scaled = cfg["use_scaled_pos_enc"]
         ff = cfg["positionwise_layer_type"]
@@ -195,7 +198,7 @@ class Engine:
         self.pdim, self.edim = self.wp.shape[1], self.we.shape[1]
         self.w_out = pack_gemm_weight(g("feat_out.weight"), self.dec_code)
         self.b_out = g("feat_out.bias")
-        self.odim = self.b_out.shape[0]
+        self.odim = self.b_out.shape[0] // self.r
         # repaired PostNet: eval-mode BatchNorm folded into the conv (scale on W, shift as bias)
         self.postnet = []
         tdt = hip.TORCH_DTYPE[self.dec_code]
@@ -488,20 +491,32 @@ class Engine:
             yt = y32
         dec_att = [] if ctx["enc_att"] is not None else None
         z32, zt = self._run_stack(self.dec, y32, yt, seg_f, cu_frames, B, max_ol, Mf, dec_att, olens)
-        before = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim, d, 1, dc, out_f32=True, tag="feat_out")
+        r = self.r
+        before = self._gemm(zt, self.w_out, self.b_out, Mf, self.odim * r, d, 1, dc, out_f32=True, tag="feat_out")
+        # `.view(B, -1, odim)` of the reference (:219): r mel frames per decoder frame, still one packed matrix
+        Mo, cu_mel, seg_o, mel_lens = Mf, cu_frames, seg_f, olens
+        if r > 1:
+            Mo, before, mel_lens = Mf * r, before.view(Mf * r, self.odim), [n * r for n in olens]
+            cu_mel = cu_frames * r
+            if self.postnet:
+                seg_o = self._empty((max(Mo, 1), 2), dtype=torch.int32)
+                pos_o = self._empty((max(Mo, 1),), dtype=torch.int32)
+                call("fs2_build_seg", ptr(cu_mel), B, ptr(seg_o), ptr(pos_o), Mo, stream())
         mel = before
         if self.postnet:      # after = before + postnet(before)   (network/fastspeech2.py:222-225)
             cur = before
             if dc != F32:
-                cur = self._empty((Mf, self.odim), dc)
-                call("fs2_cast", ptr(before), ptr(cur), Mf * self.odim, dc, stream())
+                cur = self._empty((Mo, self.odim), dc)
+                call("fs2_cast", ptr(before), ptr(cur), Mo * self.odim, dc, stream())
             for j, L in enumerate(self.postnet):
                 last = j == len(self.postnet) - 1
-                cur = self._gemm(cur, L["w"], L["b"], Mf, L["cout"], L["cin"], L["taps"], dc,
-                                 seg=seg_f if L["taps"] > 1 else None, res=before if last else None,
+                cur = self._gemm(cur, L["w"], L["b"], Mo, L["cout"], L["cin"], L["taps"], dc,
+                                 seg=seg_o if L["taps"] > 1 else None, res=before if last else None,
                                  relu=0 if last else 2, out_f32=last)
             mel = cur
-        out = dict(mel=mel, mel_before=before, olens=olens, cu_frames=cu_frames, cu_phone=cu_phone, durations=ctx["dur_used"][:Mp],
+        # olens / cu_frames count decoder frames (pitch, energy, attention); mel_lens / cu_mel the mel rows (= r times those)
+        out = dict(mel=mel, mel_before=before, olens=olens, cu_frames=cu_frames, mel_lens=mel_lens, cu_mel=cu_mel,
+                   cu_phone=cu_phone, durations=ctx["dur_used"][:Mp],
                    durations_pred=ctx["dur_pred"][:Mp], log_durations=ctx["logd"], pitch=pitch, energy=energy,
                    lr_index=lr_index[:Mf], enc_out=hs32, frames=Mf)
         if dec_att is not None:

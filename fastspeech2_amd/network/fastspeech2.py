@@ -317,6 +317,10 @@ class FeedForwardTransformer(nn.Module):
                 out = eng.forward(ids, il, duration_control=duration_control, pitch_control=pitch_control,
                                   energy_control=energy_control)
             else:
+                if self.reduction_factor != 1:
+                    # the reference builds the decoder masks from olens // r but length-regulates to olens frames
+                    # (network/fastspeech2.py:209-215): not self-consistent, nothing to pin a result to
+                    raise NotImplementedError("reduction_factor > 1 is supported for inference only")
                 ol = [int(v) for v in olens]
                 ds_p = self._pack(ds.to(eng.dev), il).to(torch.int32).contiguous()
                 if [int(v) for v in self._segment_sums(ds_p, il)] != ol:
@@ -325,8 +329,9 @@ class FeedForwardTransformer(nn.Module):
                 es_p = self._pack(es.to(eng.dev), ol).float().contiguous()
                 out = eng.forward(ids, il, ds=ds_p, ps=ps_p, es=es_p)
             Tmax = max(out["olens"]) if B else 0
-            after = eng.unpack(out["mel"], out["cu_frames"], B, Tmax)
-            before = after if self.postnet is None else eng.unpack(out["mel_before"], out["cu_frames"], B, Tmax)
+            Tmel = max(out["mel_lens"]) if B else 0          # = reduction_factor x the decoder frames
+            after = eng.unpack(out["mel"], out["cu_mel"], B, Tmel)
+            before = after if self.postnet is None else eng.unpack(out["mel_before"], out["cu_mel"], B, Tmel)
         if _raw:
             return before, after, out
         if is_inference:
@@ -443,6 +448,8 @@ class FeedForwardTransformer(nn.Module):
         """Extension: `inference()` replays HIP graphs captured per utterance shape (engine.GraphedInference) instead
         of issuing its ~100 launches from Python: same kernels, same results, about half the batch-1 latency for
         shapes seen before.  max_graphs = 0 turns it off again."""
+        if int(max_graphs) and self.reduction_factor != 1:
+            raise NotImplementedError("inference graphs are captured for reduction_factor = 1")
         self._graph_cap = int(max_graphs)
         self._graphed = None
         return self
@@ -459,13 +466,14 @@ class FeedForwardTransformer(nn.Module):
             out = eng.forward(ids, il, duration_control=duration_control, pitch_control=pitch_control,
                               energy_control=energy_control)
             B, Tmax, Tp = len(il), max(out["olens"]), max(il)
-            mel = eng.unpack(out["mel"], out["cu_frames"], B, Tmax)
+            mel = eng.unpack(out["mel"], out["cu_mel"], B, max(out["mel_lens"]))
             dur = eng.unpack(out["durations"].float().view(-1, 1), out["cu_phone"], B, Tp).squeeze(-1).long()
             pitch = eng.unpack(out["pitch"], out["cu_frames"], B, Tmax)
             energy = eng.unpack(out["energy"], out["cu_frames"], B, Tmax)
-        olens = torch.tensor(out["olens"], dtype=torch.int64)
+        # olens: mel frames per utterance (= reduction_factor x the decoder frames that pitch / energy are given on)
+        olens = torch.tensor(out["mel_lens"], dtype=torch.int64)
         return dict(mel=mel, olens=olens, durations=dur, pitch=pitch, energy=energy,
-                    src_mask=make_non_pad_mask(il), mel_mask=make_non_pad_mask(out["olens"]), packed=out)
+                    src_mask=make_non_pad_mask(il), mel_mask=make_non_pad_mask(out["mel_lens"]), packed=out)
 
     def calculate_all_attentions(self, xs, ilens, ys, olens, ds, ps, es, **_ignored):
         """network/fastspeech2.py:305-341: dict name -> list over utterances of (h, T, T) arrays, plus

@@ -68,13 +68,14 @@ def decode(cfg, model, current_step=0, criterion=None, rank: int = 0, world_size
             before = out["mel_before"].cpu().numpy()
             dur = out["durations"].cpu().numpy()
             pitch, energy = out["pitch"].cpu().numpy(), out["energy"].cpu().numpy()
-            cu_f = np.concatenate([[0], np.cumsum(out["olens"])])
+            cu_f = np.concatenate([[0], np.cumsum(out["olens"])])         # decoder frames: pitch / energy rows
+            cu_m = np.concatenate([[0], np.cumsum(out["mel_lens"])])      # mel rows (= reduction_factor x those)
             cu_p = np.concatenate([[0], np.cumsum([lengths[i] for i in bucket])])
             for j, i in enumerate(bucket):
-                T, L = int(out["olens"][j]), lengths[i]
-                f0, f1, p0, p1 = cu_f[j], cu_f[j + 1], cu_p[j], cu_p[j + 1]
+                T, L = int(out["mel_lens"][j]), lengths[i]
+                f0, f1, p0, p1, m0, m1 = cu_f[j], cu_f[j + 1], cu_p[j], cu_p[j + 1], cu_m[j], cu_m[j + 1]
                 results[ids[i]] = dict(
-                    mel=before[f0:f1], mel_postnet=mel[f0:f1], durations=dur[p0:p1].astype(np.int64),
+                    mel=before[m0:m1], mel_postnet=mel[m0:m1], durations=dur[p0:p1].astype(np.int64),
                     pitch=pitch[f0:f1], energy=energy[f0:f1], src_mask=np.ones(L, bool), mel_mask=np.ones(T, bool),
                     mel_length=T)
     out_npz = _get(cfg, "DECODE.OUT_NPZ")

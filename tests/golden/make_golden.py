@@ -197,6 +197,10 @@ def main():
     if only:            # python tests/golden/make_golden.py long_512 train_baseline_b32 : just these (new) fixtures
         if "long_512" in only:
             run_long_case("long_512", BASELINE, 1234, math.log(8.8), 512, 0.15)
+        if "reduction2_tiny" in only:
+            run_inference_case("reduction2_tiny", dict(TINY_B, reduction_factor=2), 18, math.log(3.0), [3, 19, 28], alpha=0.9)
+        if "reduction3_postnet" in only:
+            run_inference_case("reduction3_postnet", dict(POSTNET_TINY, reduction_factor=3), 19, math.log(2.5), [5, 22])
         if "train_baseline_b32" in only:
             run_train_case("train_baseline_b32", BASELINE, 1234, math.log(7.67), B=32, Tp=120, ds_lo=1, ds_hi=13,
                            store_inputs=False)
@@ -211,6 +215,8 @@ def main():
     run_inference_case("baseline_4x4", BASELINE, 1234, math.log(7.67), [120, 61])
     run_inference_case("postnet_tiny_bn", POSTNET_TINY, 15, math.log(3.0), [4, 21, 30], alpha=0.9)
     run_inference_case("postnet_tiny_nobn", POSTNET_NOBN, 16, math.log(3.0), [9, 17], alpha=1.0)
+    run_inference_case("reduction2_tiny", dict(TINY_B, reduction_factor=2), 18, math.log(3.0), [3, 19, 28], alpha=0.9)
+    run_inference_case("reduction3_postnet", dict(POSTNET_TINY, reduction_factor=3), 19, math.log(2.5), [5, 22])
     import yaml
     shipped = dict(YAML_SHIPPED, **yaml.safe_load(open(os.path.join(ROOT, "fastspeech2_amd", "param", "fastspeech.yaml"))))
     run_inference_case("yaml_shipped_full", shipped, 17, math.log(4.0), [25, 12])

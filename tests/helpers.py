@@ -15,7 +15,8 @@ LONG_CASES = ["long_512"]            # BASELINE config 4: 512 phones -> ~4000 fr
 BIG_TRAIN_CASES = ["train_baseline_b32"]   # BASELINE config 5 shapes: inputs regenerated from the seed (train_inputs)
 INFER_CASES = ["tiny_conv9_plain", "tiny_linear_scaled", "tiny_conv3_mixed_ln", "yaml_dims_2x2",
                "d9_zero_durations", "duration_control_0p8", "duration_control_1p3", "baseline_4x4",
-               "postnet_tiny_bn", "postnet_tiny_nobn", "yaml_shipped_full"]
+               "postnet_tiny_bn", "postnet_tiny_nobn", "yaml_shipped_full",
+               "reduction2_tiny", "reduction3_postnet"]      # reduction_factor 2 / 3 (the latter through the PostNet)
 TRAIN_CASES = ["train_tiny_conv9", "train_tiny_linear", "train_postnet_tiny", "train_tiny_conv3_mixed"]
 GRAD_CASES = ["train_tiny_conv9", "train_tiny_linear", "train_tiny_conv3_mixed"]
 
