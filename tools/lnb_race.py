@@ -16,7 +16,7 @@ ws = torch.empty(lib.fs2_layernorm_bwd_workspace(M, C) // 4 + 4, device=dev)
 N, Cin = int(os.environ.get("WN", "768")), 256
 gy = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16); gx = torch.randn(M, Cin, device=dev, generator=g).to(torch.bfloat16)
 gw = torch.empty(N, Cin, device=dev); gb = torch.empty(N, device=dev)
-ks = 8
+ks = int(os.environ.get("WKS", "8"))
 wws = torch.empty(lib.fs2_conv_wgrad_workspace(N, Cin, 1, ks) // 4 + 4, device=dev)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 # the producer of `parts` in a training step: da = dqkv . Wqkv as a split-K GEMM (fp32 partials)
@@ -24,19 +24,40 @@ dq = torch.randn(M, 3 * C, device=dev, generator=g).to(torch.bfloat16)
 wq = (torch.randn(1, C, 3 * C, device=dev, generator=g) / 16).to(torch.bfloat16)
 ksg = int(lib.fs2_conv_gemm_ksplit(M, C, 3 * C, 1, 1))
 print("split-K factor of the producer GEMM:", ksg)
+ta = torch.randn(4096, 2048, device=dev).to(torch.bfloat16); tb = torch.randn(2048, 4096, device=dev).to(torch.bfloat16)
+tc = torch.empty(4096, 4096, device=dev, dtype=torch.bfloat16)
+cg_out = torch.empty(M, C, device=dev)
+import numpy as np
+aq = torch.randn(M, 768, device=dev).to(torch.bfloat16); actx = torch.empty(M, 256, device=dev, dtype=torch.bfloat16)
+acu = torch.tensor(np.arange(33) * 843, dtype=torch.int32, device=dev)
+fixed_parts = os.environ.get("FIXED_PARTS", "0") == "1"
+parts0 = torch.randn(1, M, C, device=dev, generator=g)
 outs = []
 torch.cuda.synchronize()
 NL = int(os.environ.get("NL", "200"))
 for it in range(NL):
-    if busy:
+    if busy == 3:          # another LDS-DMA aggressor: the k = 1 conv_gemm (QKV shape)
+        for _ in range(3):
+            call("fs2_conv_gemm", ptr(dq), ptr(wq), None, None, ptr(cg_out), None, M, C, 3 * C, 1, 3 * C, C, C, 0, 1, 1, 1, M * C,
+                 hip.c_void_p(sb.cuda_stream))
+    elif busy == 4:        # attention (LDS-DMA + MFMA + transposed reads)
+        call("fs2_attention", ptr(aq), ptr(actx), ptr(acu), 32, 843, 2, 128, 768, 256, 1, hip.c_void_p(sb.cuda_stream))
+    elif busy == 2:          # another aggressor: plain torch GEMMs on the other stream
+        with torch.cuda.stream(sb):
+            for _ in range(3):
+                torch.mm(ta, tb, out=tc)
+    elif busy:
         for _ in range(3):
             call("fs2_conv_wgrad", ptr(gy), ptr(gx), ptr(gw), ptr(gb), ptr(wws), None, M, N, Cin, 1, N, Cin, 1, ks, 1.0, 0,
                  hip.c_void_p(sb.cuda_stream))
     of = torch.empty(M, C, device=dev); ot = torch.empty(M, C, device=dev, dtype=torch.bfloat16); dw = torch.empty(2 * C, device=dev)
     with torch.cuda.stream(sa):
         parts = torch.empty(ksg, M, C, device=dev)
-    call("fs2_conv_gemm", ptr(dq), ptr(wq), None, None, ptr(parts), None, M, C, 3 * C, 1, 3 * C, C, C, 0, 1, 1, ksg, M * C,
-         hip.c_void_p(sa.cuda_stream))
+    if fixed_parts:
+        parts = parts0
+    else:
+        call("fs2_conv_gemm", ptr(dq), ptr(wq), None, None, ptr(parts), None, M, C, 3 * C, 1, 3 * C, C, C, 0, 1, 1, ksg, M * C,
+             hip.c_void_p(sa.cuda_stream))
     call("fs2_layernorm_bwd", ptr(x), ptr(dy), ptr(parts), ksg, M * C, ptr(w), None, 0, ptr(of), ptr(ot), ptr(dw),
          hip.c_void_p(dw.data_ptr() + 4 * C), ptr(ws), M, C, 1e-12, 0, 1, 7, 1, 0.0, 2, 0.0, hip.c_void_p(sa.cuda_stream))
     outs.append((of, ot, dw, parts))
