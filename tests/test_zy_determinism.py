@@ -48,13 +48,13 @@ def test_inference_repeats_are_bit_identical(precision, encoder):
 
 
 def test_training_step_repeats_are_bit_identical():
-    """BASELINE config 5 (B = 32, 4+4 blocks, d = 256, conv k = 9), bf16, dropout off: loss and all gradients of two
+    """BASELINE config 5 (B = 32, 4+4 blocks, d = 256, conv k = 9), bf16, dropout off: loss and all gradients of three
     runs of the same step, bit for bit (every gradient has one writer and a fixed summation order)."""
     z, meta = helpers.load_golden(helpers.BIG_TRAIN_CASES[0])
     batch = [torch.from_numpy(a) for a in helpers.train_inputs(meta["cfg"], meta["seed"], **meta["inputs"])]
     from tests.test_gpu_train import _model
     runs = []
-    for _ in range(2):
+    for _ in range(3):
         model = _model(meta, "bf16")
         model.dropout_enabled = False
         loss = model(*batch)
@@ -62,6 +62,7 @@ def test_training_step_repeats_are_bit_identical():
         torch.cuda.synchronize()
         runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
         del model
-    assert torch.equal(runs[0][0], runs[1][0])
-    for k in runs[0][1]:
-        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0])
+        for k in runs[0][1]:
+            assert torch.equal(runs[0][1][k], other[1][k]), k
