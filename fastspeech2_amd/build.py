@@ -24,6 +24,15 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def extra_flags(src: str):
+    """Per-file compiler flags, declared in the source itself on a line `// FS2_HIPCC_FLAGS: ...` (first 60 lines)."""
+    with open(src) as f:
+        for _, line in zip(range(60), f):
+            if "FS2_HIPCC_FLAGS:" in line:
+                return line.split("FS2_HIPCC_FLAGS:", 1)[1].split()
+    return []
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
@@ -32,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in sources():
         obj = src[:-4] + ".o"
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-c", src, "-o", obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", CSRC] + extra_flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -3,6 +3,14 @@
 // LengthRegulator backward (segment sum), embedding backward, loss gradients and weight packing.
 // What autograd's backward of the reference modules computes (run/train_decode.py:94-97 calls
 // loss.backward() on network/fastspeech2.py:232-295) restated over the packed ragged layout.
+//
+// FS2_HIPCC_FLAGS: -fno-slp-vectorize
+// (built without the SLP vectoriser.  With it, hipcc (ROCm 7.2) packs the per-row scalar arithmetic of layernorm_bwd —
+// rows taken several at a time — into v_pk_*_f32 instructions with SGPR-pair / op_sel operands, and a wave of that code
+// sharing a SIMD with another kernel's v_mfma_f32_16x16x32_bf16 (fs2_conv_wgrad on the other stream of a training step:
+// its two waves per SIMD leave room for such a wave; conv_gemm / attention fill the register file) now and then
+// computed a whole row wrong: tools/lnb_race.py, 1200-1700 differing outputs in 600 launches with the vectoriser on this
+// file, 0 without; with it on conv_wgrad.hip only it made no difference.  DESIGN.md section 4.3.)
 #include "common.h"
 #include "../../include/fs2_pack_desc.h"
 
@@ -20,11 +28,6 @@ constexpr int LNB_ROWS = FS2_LNB_ROWS;   // rows per workgroup (4 waves x LNB_RO
 // Per-workgroup partial sums of d gamma = sum g * xh and d beta = sum g go to wb_part[blk][2][C].
 // NV = float4 per lane (C <= 256 NV); the dγ/dβ staging in LDS is sized to C (dynamic: 8 C floats), so that the
 // kernel's workgroups fit beside the 100 KB conv_wgrad workgroup that shares the CU during a training step.
-// (A form that took a wave's rows four at a time — 16 loads in flight per lane, interleaved reductions, 137 VGPRs / 99
-// SGPRs with SGPR spills — was 20-30 % faster beside conv_wgrad and is NOT kept: about once in 100-200 launches, and only
-// while another kernel shared the CUs, single rows of its output came out wrong (tools/lnb_race.py reproduces it at the
-// kernel level: always the second row of a group; this one-row form: 0 in 400).  No cause was found in the source or
-// the ISA; tests/test_zy_determinism.py and tools/train_determinism_check.py are what caught it.)
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ parts, int nparts,
@@ -39,94 +42,143 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float red[];      // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cv = C >> 2;
-    f32x4 dgam[NV], dbet[NV];
+    // A wave takes its LNB_ROWS / 4 rows R at a time: the loads of R rows (incoming gradient, partials, x, residual
+    // gradient) are requested together and their reductions interleave.  One row at a time, a wave had one row's few
+    // 16-byte loads in flight between dependent reductions, and beside conv_wgrad on the other stream of a training
+    // step (which fills the memory system) the frame-level launches took 93 us against 25-33 us alone.  Rows are still
+    // accumulated into d gamma / d beta in ascending order: the sums are bit-identical to the one-row form's.
+    constexpr int R = NV == 1 ? 4 : (NV == 2 ? 2 : 1);
+    static_assert((LNB_ROWS / 4) % R == 0, "rows per wave in groups of R");
+    f32x4 dgam[NV], dbet[NV], wv[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) dgam[k] = dbet[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NV; ++k) {
+        dgam[k] = dbet[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int j = lane + k * 64;
+        wv[k] = (w && j < cv) ? *(const f32x4*)(w + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const float invC = 1.0f / (float)C;
-    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
-        const int row = blockIdx.x * LNB_ROWS + rr * 4 + wave;
-        if (row >= M) break;
-        const size_t roff = (size_t)row * C;
-        f32x4 xv[NV], gv[NV];
-        float s = 0.f;
+    for (int rr = 0; rr < LNB_ROWS / 4; rr += R) {
+        const int row0 = blockIdx.x * LNB_ROWS + rr * 4 + wave;
+        if (row0 >= M) break;
+        int rows[R];
+        bool live[R];
+        size_t roff[R];
+        f32x4 xv[R][NV], gv[R][NV], rv[R][NV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = lane + k * 64;
-            if (j < cv) {
-                f32x4 t = dy ? *(const f32x4*)(dy + roff + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
-                if (din.thresh) {
+        for (int i = 0; i < R; ++i) {
+            rows[i] = row0 + 4 * i;
+            live[i] = rows[i] < M;                                   // a missing row reads the last one and writes nothing
+            roff[i] = (size_t)(live[i] ? rows[i] : M - 1) * C;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) t[r] *= drop_mul(din, (uint32_t)row, (uint32_t)(j * 4 + r));
-                }
-                gv[k] = t;
-                if (x) {
-                    xv[k] = *(const f32x4*)(x + roff + j * 4);
-                    s += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
-                }
+            for (int k = 0; k < NV; ++k) {
+                const int j = lane + k * 64;
+                const bool ok = j < cv;
+                gv[i][k] = (dy && ok) ? *(const f32x4*)(dy + roff[i] + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                xv[i][k] = (x && ok) ? *(const f32x4*)(x + roff[i] + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                rv[i][k] = (dres && ok) ? *(const f32x4*)(dres + roff[i] + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
+        for (int p = 0; p < nparts; ++p) {
+            const float* pp = parts + (size_t)p * part_stride;
+            f32x4 t[R][NV];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int j = lane + k * 64;
+                    t[i][k] = j < cv ? *(const f32x4*)(pp + roff[i] + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) gv[i][k] += t[i][k];
+        }
+        if (din.thresh) {
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        gv[i][k][r] *= drop_mul(din, (uint32_t)rows[i], (uint32_t)((lane + k * 64) * 4 + r));
+        }
+        float mean[R], rstd[R], m1[R], m2[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            mean[i] = 0.f; rstd[i] = 1.f; m1[i] = 0.f; m2[i] = 0.f;
+        }
         if (w) {
-            mean = wave_sum(s) * invC;
-            float q = 0.f;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int j = lane + k * 64;
-                if (j < cv) {
+            for (int i = 0; i < R; ++i) {
+                float s = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float dlt = xv[k][r] - mean;
-                        q += dlt * dlt;
-                    }
-                }
+                for (int k = 0; k < NV; ++k) s += (xv[i][k][0] + xv[i][k][1]) + (xv[i][k][2] + xv[i][k][3]);   // lanes beyond the row hold zeros
+                mean[i] = wave_sum(s) * invC;
             }
-            rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
-            float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int j = lane + k * 64;
-                if (j < cv) {
-                    const f32x4 ww = *(const f32x4*)(w + j * 4);
+            for (int i = 0; i < R; ++i) {
+                float q = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float xh = (xv[k][r] - mean) * rstd;
-                        const float h = gv[k][r] * ww[r];
-                        a1 += h;
-                        a2 += h * xh;
-                        dgam[k][r] += gv[k][r] * xh;
-                        dbet[k][r] += gv[k][r];
+                for (int k = 0; k < NV; ++k)
+                    if (lane + k * 64 < cv) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float dlt = xv[i][k][r] - mean[i];
+                            q += dlt * dlt;
+                        }
                     }
-                }
+                rstd[i] = 1.0f / sqrtf(wave_sum(q) * invC + eps);
             }
-            m1 = wave_sum(a1) * invC;
-            m2 = wave_sum(a2) * invC;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    if (lane + k * 64 < cv) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (xv[i][k][r] - mean[i]) * rstd[i];
+                            const float h = gv[i][k][r] * wv[k][r];
+                            a1 += h;
+                            a2 += h * xh;
+                            if (live[i]) {
+                                dgam[k][r] += gv[i][k][r] * xh;
+                                dbet[k][r] += gv[i][k][r];
+                            }
+                        }
+                    }
+                m1[i] = wave_sum(a1) * invC;
+                m2[i] = wave_sum(a2) * invC;
+            }
         }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int j = lane + k * 64;
-            if (j < cv) {
-                f32x4 o = gv[k];
-                if (w) {
-                    const f32x4 ww = *(const f32x4*)(w + j * 4);
+        for (int i = 0; i < R; ++i) {
+            if (!live[i]) continue;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float xh = (xv[k][r] - mean) * rstd;
-                        o[r] = rstd * (gv[k][r] * ww[r] - m1 - xh * m2);
+            for (int k = 0; k < NV; ++k) {
+                const int j = lane + k * 64;
+                if (j < cv) {
+                    f32x4 o = gv[i][k];
+                    if (w) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (xv[i][k][r] - mean[i]) * rstd[i];
+                            o[r] = rstd[i] * (gv[i][k][r] * wv[k][r] - m1[i] - xh * m2[i]);
+                        }
                     }
-                }
-                if (dres) o += *(const f32x4*)(dres + roff + j * 4);
-                if (relu_gate) {
+                    if (dres) o += rv[i][k];
+                    if (relu_gate) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = xv[k][r] > 0.f ? o[r] : 0.f;
-                }
-                if (dx_f32) *(f32x4*)(dx_f32 + roff + j * 4) = o;
-                if (dx_t) {
-                    if (dto.thresh) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] *= drop_mul(dto, (uint32_t)row, (uint32_t)(j * 4 + r));
+                        for (int r = 0; r < 4; ++r) o[r] = xv[i][k][r] > 0.f ? o[r] : 0.f;
                     }
-                    store4<T>(dx_t + roff + j * 4, o);
+                    if (dx_f32) *(f32x4*)(dx_f32 + roff[i] + j * 4) = o;
+                    if (dx_t) {
+                        if (dto.thresh) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] *= drop_mul(dto, (uint32_t)rows[i], (uint32_t)(j * 4 + r));
+                        }
+                        store4<T>(dx_t + roff[i] + j * 4, o);
+                    }
                 }
             }
         }

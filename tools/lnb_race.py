@@ -16,6 +16,9 @@ ws = torch.empty(lib.fs2_layernorm_bwd_workspace(M, C) // 4 + 4, device=dev)
 N, Cin = int(os.environ.get("WN", "768")), 256
 gy = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16); gx = torch.randn(M, Cin, device=dev, generator=g).to(torch.bfloat16)
 gw = torch.empty(N, Cin, device=dev); gb = torch.empty(N, device=dev)
+wdt = int(os.environ.get("WDT", "1"))            # aggressor operand type: 1 bf16, 0 fp32
+nobias = os.environ.get("WNOBIAS", "0") == "1"   # aggressor without the bias-gradient path
+gy32, gx32 = (gy.float(), gx.float()) if wdt == 0 else (None, None)
 ks = int(os.environ.get("WKS", "8"))
 wws = torch.empty(lib.fs2_conv_wgrad_workspace(N, Cin, 1, ks) // 4 + 4, device=dev)
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
@@ -48,8 +51,8 @@ for it in range(NL):
                 torch.mm(ta, tb, out=tc)
     elif busy:
         for _ in range(3):
-            call("fs2_conv_wgrad", ptr(gy), ptr(gx), ptr(gw), ptr(gb), ptr(wws), None, M, N, Cin, 1, N, Cin, 1, ks, 1.0, 0,
-                 hip.c_void_p(sb.cuda_stream))
+            call("fs2_conv_wgrad", ptr(gy32 if wdt == 0 else gy), ptr(gx32 if wdt == 0 else gx), ptr(gw),
+                 None if nobias else ptr(gb), ptr(wws), None, M, N, Cin, 1, N, Cin, wdt, ks, 1.0, 0, hip.c_void_p(sb.cuda_stream))
     of = torch.empty(M, C, device=dev); ot = torch.empty(M, C, device=dev, dtype=torch.bfloat16); dw = torch.empty(2 * C, device=dev)
     with torch.cuda.stream(sa):
         parts = torch.empty(ksg, M, C, device=dev)
