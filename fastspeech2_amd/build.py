@@ -10,6 +10,11 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libfs2_gfx950.so")
 ARCH = "gfx950"
+# -fno-slp-vectorize: with the SLP vectoriser hipcc (ROCm 7.2) packs adjacent scalar fp32 arithmetic into v_pk_*_f32
+# instructions (SGPR-pair / op_sel operands); such code in layernorm_bwd computed whole rows wrong, now and then, when its
+# wave shared a SIMD with another kernel's bf16 MFMAs (tools/lnb_race.py).  Off for every file:
+# no measurable cost (bench.py / bench_train.py A/B/A/B; the attention launches gain 1-2 %).
+BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"]
 
 
 def sources():
@@ -41,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in sources():
         obj = src[:-4] + ".o"
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", CSRC] + extra_flags(src) + ["-c", src, "-o", obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH] + BASE_FLAGS + ["-I", CSRC] + extra_flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -4,13 +4,12 @@
 // What autograd's backward of the reference modules computes (run/train_decode.py:94-97 calls
 // loss.backward() on network/fastspeech2.py:232-295) restated over the packed ragged layout.
 //
-// FS2_HIPCC_FLAGS: -fno-slp-vectorize
-// (built without the SLP vectoriser.  With it, hipcc (ROCm 7.2) packs the per-row scalar arithmetic of layernorm_bwd —
+// Built without the SLP vectoriser (-fno-slp-vectorize is among the base flags of fastspeech2_amd/build.py).  With it, hipcc (ROCm 7.2) packs the per-row scalar arithmetic of layernorm_bwd —
 // rows taken several at a time — into v_pk_*_f32 instructions with SGPR-pair / op_sel operands, and a wave of that code
 // sharing a SIMD with another kernel's v_mfma_f32_16x16x32_bf16 (fs2_conv_wgrad on the other stream of a training step:
 // its two waves per SIMD leave room for such a wave; conv_gemm / attention fill the register file) now and then
 // computed a whole row wrong: tools/lnb_race.py, 1200-1700 differing outputs in 600 launches with the vectoriser on this
-// file, 0 without; with it on conv_wgrad.hip only it made no difference.  DESIGN.md section 4.3.)
+// file, 0 without; with it on conv_wgrad.hip only it made no difference.  DESIGN.md section 4.3.
 #include "common.h"
 #include "../../include/fs2_pack_desc.h"
 

@@ -7,11 +7,6 @@
 //   fs2_bn_bwd        dgamma, dbeta and dY = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)), dz = the gradient
 //                     behind dropout and tanh (recomputed from y: nothing but y and the statistics is kept)
 // stats == null means "no BatchNorm" (use_batch_norm=False): identity normalisation, dY = dz.
-//
-// FS2_HIPCC_FLAGS: -fno-slp-vectorize
-// (no SLP vectoriser for the row kernels, as a precaution: the packed v_pk_*_f32 arithmetic it forms out of per-row scalars
-// miscomputed beside another wave's bf16 MFMAs in backward.hip, see the note there and DESIGN.md section 4.3.  These kernels
-// showed no such effect (tools/hbm_race.py) and the flag costs them nothing: A/B/A/B of bench.py and bench_hbm_kernels.py.)
 #include "common.h"
 
 namespace fs2 {

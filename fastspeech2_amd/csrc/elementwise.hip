@@ -3,11 +3,6 @@
 // variance-embedding add fused with the decoder positional encoding, and packed<->padded moves.
 // All activations are packed ragged matrices [rows, channels], channel-last, fp32 residual stream
 // with an optional low-precision (bf16) copy for the MFMA kernels.
-//
-// FS2_HIPCC_FLAGS: -fno-slp-vectorize
-// (no SLP vectoriser for the row kernels, as a precaution: the packed v_pk_*_f32 arithmetic it forms out of per-row scalars
-// miscomputed beside another wave's bf16 MFMAs in backward.hip, see the note there and DESIGN.md section 4.3.  These kernels
-// showed no such effect (tools/hbm_race.py) and the flag costs them nothing: A/B/A/B of bench.py and bench_hbm_kernels.py.)
 #include "common.h"
 #include <stdlib.h>
 

@@ -8,7 +8,7 @@ objs=""
 for src in fastspeech2_amd/csrc/*.hip; do
   o=variants/obj_$tag/$(basename ${src%.hip}).o
   extra=$(head -60 $src | grep -m1 "FS2_HIPCC_FLAGS:" | sed 's/.*FS2_HIPCC_FLAGS://' || true)   # per-file flags (fastspeech2_amd/build.py)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I fastspeech2_amd/csrc $extra "$@" -c $src -o $o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I fastspeech2_amd/csrc $extra "$@" -c $src -o $o &   # base flags = fastspeech2_amd/build.py BASE_FLAGS
   objs="$objs $o"
 done
 wait
