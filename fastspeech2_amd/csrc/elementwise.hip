@@ -131,10 +131,63 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     }
 }
 
-// (A four-rows-per-wave form of this kernel, one row per 16-lane group as in layernorm_rowdot_kernel below with
-// (1 + nparts) * C / 64 loads in flight per lane, measured 21.4 / 28.4 us against 19.5 / 28.0 us here at 24.7 k x 256
-// with 1 / 3 partials over rotating buffers: at 4.5-4.9 TB/s of algorithmic bytes this kernel already moves 72-78 % of
-// the 6.3 TB/s a float4 copy reaches on this part (MI355X_MICROARCH.md); not kept.)
+// The same operation, one wave per four consecutive rows, ONE ROW PER 16-LANE GROUP (as layernorm_rowdot_kernel below):
+// a lane holds NV = C / 64 float4 columns of its row, (1 + nparts) * NV 16-byte loads are in flight per lane and the two
+// reductions of four rows are four DPP steps each.  Partials are added in the same order as above; the statistics are
+// summed in another lane order (fp32 rounding-level differences), so the exact-duration modes keep the form above.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void add_layernorm_rows4_kernel(const float* __restrict__ x, const float* __restrict__ parts,
+                                                                  int nparts, long long part_stride,
+                                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                                  float* sum_out, float* out_f32, T* __restrict__ out_t,
+                                                                  int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, quarter = lane >> 4;
+    const int grp = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int row = grp * 4 + quarter;
+    if (grp * 4 >= M) return;
+    const bool live = row < M;
+    const size_t roff = (size_t)(live ? row : M - 1) * C;      // lanes of a missing row read the last one and store nothing
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        v[k] = x ? *(const f32x4*)(x + roff + (sub + k * 16) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < nparts; ++p) {
+        const float* pp = parts + (size_t)p * part_stride + roff;
+        f32x4 t[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) t[k] = *(const f32x4*)(pp + (sub + k * 16) * 4);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += t[k];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (sum_out && live) *(f32x4*)(sum_out + roff + (sub + k * 16) * 4) = v[k];
+        s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    }
+    const float mean = row16_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dlt = v[k][r] - mean;
+            q += dlt * dlt;
+        }
+    const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = (sub + k * 16) * 4;
+        const f32x4 ww = *(const f32x4*)(w + c);
+        const f32x4 bb = *(const f32x4*)(b + c);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
+        if (out_f32) *(f32x4*)(out_f32 + roff + c) = o;
+        if (out_t) store4<T>(out_t + roff + c, o);
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // tiny heads: out[m, j] = x[m, :] . W[j, :] + b[j], j < NOUT <= 8, fp32 (predictor `linear`,
@@ -679,10 +732,24 @@ static int add_layernorm_entry(const float* x, const float* parts, int nparts, l
                       "fs2_add_layernorm(f16x3): C=%d must be a multiple of 32 and out_t 128-byte aligned", C);
         hipLaunchKernelGGL(add_layernorm_kernel<f16pair_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
                            part_stride, w, b, sum_out, out_f32, (f16pair_t*)out_t, M, C, eps, dparts, dout);
-    } else if (dtype == 1)
-        hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
-                           part_stride, w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps, dparts, dout);
-    else
+    } else if (dtype == 1) {
+        // frame-level launches (bf16 copies, no dropout): four rows per wave.  Alone it is no faster (21.4 / 28.4 us against
+        // 19.5 / 28.0 us at 24.7 k x 256 with 1 / 3 partials: the kernel moves 72-78 % of the copy rate either way); beside
+        // the GEMMs of the other streams in the throughput loop it is: bench.py A/B/A/B/A/B 1.827-1.830 -> 1.808-1.826 ms
+        // per step (exact mode), 1.660-1.678 -> 1.633-1.653 (pure bf16).  FS2_LN_ROWS4=0: the one-row form.
+        static const int rows4 = getenv("FS2_LN_ROWS4") ? atoi(getenv("FS2_LN_ROWS4")) : 1;
+        const bool fast = rows4 && w && !dparts.thresh && !dout.thresh && (C == 256 || C == 384) && M >= 1024;
+        const dim3 g4(blocks_for((M + 3) / 4, 4));
+        if (fast && C == 256)
+            hipLaunchKernelGGL((add_layernorm_rows4_kernel<bf16_t, 4>), g4, dim3(256), 0, stream, x, parts, nparts, part_stride,
+                               w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps);
+        else if (fast)
+            hipLaunchKernelGGL((add_layernorm_rows4_kernel<bf16_t, 6>), g4, dim3(256), 0, stream, x, parts, nparts, part_stride,
+                               w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps);
+        else
+            hipLaunchKernelGGL(add_layernorm_kernel<bf16_t>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
+                               part_stride, w, b, sum_out, out_f32, (bf16_t*)out_t, M, C, eps, dparts, dout);
+    } else
         hipLaunchKernelGGL(add_layernorm_kernel<float>, dim3(blocks_for(M, 4)), dim3(256), 0, stream, x, parts, nparts,
                            part_stride, w, b, sum_out, out_f32, (float*)out_t, M, C, eps, dparts, dout);
     FS2_CHECK_LAUNCH("fs2_add_layernorm");

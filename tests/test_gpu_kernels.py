@@ -280,8 +280,9 @@ def test_layernorm(C):
 @pytest.mark.parametrize("C,nparts,with_x,pre_ln", [(256, 3, True, False), (256, 1, False, False), (384, 0, True, False),
                                                     (256, 2, True, True), (512, 1, True, False), (64, 1, True, False)])
 def test_add_layernorm_partials_many_rows(C, nparts, with_x, pre_ln):
-    # residual + split-K partials + LayerNorm over many rows (M % 4 != 0: partly filled last workgroup), bf16 and fp32 copies
-    # against fp64; the bf16 and the fp32 launch must agree on the fp32 output and on the pre-LN sum.
+    # residual + split-K partials + LayerNorm over many rows (M % 4 != 0: partly filled last group), bf16 and fp32 copies
+    # against fp64.  The bf16 launch of >= 1024 rows takes add_layernorm_rows4_kernel (C = 256 / 384; one row per 16-lane
+    # group), the fp32 launch the one-wave-per-row kernel: they must agree on the fp32 output and on the pre-LN sum.
     g = torch.Generator().manual_seed(C + nparts)
     M = 1030 + 1
     x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(DEV)
