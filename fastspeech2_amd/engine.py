@@ -51,6 +51,19 @@ def pack_gemm_weight(w: torch.Tensor, code: int) -> torch.Tensor:
     return out
 
 
+def pack_tiled_weight(w_packed: torch.Tensor, code: int):
+    """The pre-tiled operand of fs2_conv_gemm256 (csrc/conv_gemm256.hip) from a weight already in fs2_conv_gemm's
+    [k][N][C] layout, or None where that kernel does not serve the shape (bf16, k = 9 or 3, N % 256 == 0, C % 64 == 0)."""
+    if code != hip.BF16 or w_packed.dim() != 3:
+        return None
+    k, N, C = w_packed.shape
+    if hip.load().fs2_conv_gemm256_plan(1 << 20, int(N), int(C), int(k), code, 0) < 1:
+        return None
+    out = torch.empty_like(w_packed)
+    call("fs2_pack_weight_tiled", ptr(w_packed), ptr(out), int(N), int(C), int(k), code, stream())
+    return out
+
+
 class _NoTimer:
     def __enter__(self):
         return self
@@ -102,6 +115,9 @@ class _Stack:
             w1, w2 = f32(p + "feed_forward.w1.weight"), f32(p + "feed_forward.w2.weight")
             L["taps"] = w1.shape[-1] if ff_type == "conv1d" else 1
             L["w1"], L["w2"] = pack_gemm_weight(w1, gc), pack_gemm_weight(w2, gc)
+            # the FFN convs of the big frame-level batches run on the 256 x 256 persistent kernel from pre-tiled weights
+            L["w1_tiled"] = pack_tiled_weight(L["w1"], gc) if ff_type == "conv1d" else None
+            L["w2_tiled"] = pack_tiled_weight(L["w2"], gc) if ff_type == "conv1d" else None
             L["b1"], L["b2"] = f32(p + "feed_forward.w1.bias"), f32(p + "feed_forward.w2.bias")
             L["units"] = L["b1"].shape[0]
             for n in ("norm1", "norm2"):
@@ -212,6 +228,8 @@ class Engine:
                 w = w * scale.view(-1, 1, 1)
             self.postnet.append(dict(w=pack_gemm_weight(w, self.dec_code), b=bias.contiguous(), taps=w.shape[-1],
                                      cout=w.shape[0], cin=w.shape[1]))
+        import os
+        self.big_tiles = os.environ.get("FS2_BIG_TILES", "1") != "0"     # A/B switch of the 256 x 256 FFN-conv kernel
         self._pe = None
         self.profile = None     # optional list collecting (tag, kind, work, start_event, end_event): bench.py rooflines
 
@@ -239,6 +257,27 @@ class Engine:
         decoding, the narrow second FFN conv).  Only used where an add+LayerNorm kernel consumes the partials.
         The rule lives beside the kernel dispatch (csrc/conv_gemm.hip: fs2_conv_gemm_ksplit)."""
         return int(hip.load().fs2_conv_gemm_ksplit(int(M), int(N), int(Cin), int(taps), int(code)))
+
+    def _ffn_conv(self, x, L, which, M, N, Cin, taps, code, seg, res=None, relu=False, out_f32=False, tag=None,
+                  split=False):
+        """One FFN conv (network/encoder.py:28-30): on fs2_conv_gemm256 where it serves the shape and the batch is big
+        enough (it decides its own number of K ranges), else on fs2_conv_gemm.  split: the caller sums fp32 partials."""
+        wt = L.get(which + "_tiled")
+        ks = 0
+        if wt is not None and self.big_tiles and seg is not None:
+            ks = int(hip.load().fs2_conv_gemm256_plan(int(M), int(N), int(Cin), int(taps), int(code), 1 if split else 0))
+        if ks < 1:
+            return self._gemm(x, L[which], L["b" + which[1]], M, N, Cin, taps, code, seg=seg, res=res, relu=relu,
+                              out_f32=out_f32, tag=tag, ksplit=self._ksplit(M, N, Cin, taps, code) if split else 1)
+        shape = (ks, M, N) if split else (M, N)
+        out = self._empty(shape, dtype=torch.float32 if out_f32 else hip.TORCH_DTYPE[code])
+        if tag is not None and self.profile is not None:
+            tag = "%s:bf16" % tag
+        nbytes = M * Cin * 2.0 + taps * N * Cin * 2.0 + ks * M * N * (4.0 if out_f32 else 2.0) + (M * N * 4.0 if res is not None else 0.0)
+        with self._timed(tag, "flop", 2.0 * M * N * Cin * taps, nbytes):
+            call("fs2_conv_gemm256", ptr(x), ptr(wt), ptr(L["b" + which[1]]), ptr(res), ptr(out), ptr(seg), M, N, Cin, taps,
+                 Cin, N, N, int(relu), int(out_f32), code, ks, M * N, stream())
+        return out
 
     def _gemm(self, x, w, bias, M, N, Cin, taps, code, seg=None, res=None, relu=False, out_f32=False, tag=None,
               ksplit=1, out=None):
@@ -321,9 +360,8 @@ class Engine:
                 f_t = xt
             taps, U = L["taps"], L["units"]
             sg = seg if taps > 1 else None
-            hdn = self._gemm(f_t, L["w1"], L["b1"], M, U, d, taps, code, seg=sg, relu=True, tag="ffn1")
-            pend = self._gemm(hdn, L["w2"], L["b2"], M, d, U, taps, code, seg=sg, out_f32=True, tag="ffn2", res=x32,
-                              ksplit=self._ksplit(M, d, U, taps, code))
+            hdn = self._ffn_conv(f_t, L, "w1", M, U, d, taps, code, sg, relu=True, tag="ffn1")
+            pend = self._ffn_conv(hdn, L, "w2", M, d, U, taps, code, sg, out_f32=True, tag="ffn2", res=x32, split=True)
             if not st.pre_ln:
                 x32, xt = self._ln(None, L["norm2_w"], L["norm2_b"], M, d, code, True, True, parts=pend)
                 pend = None
