@@ -49,6 +49,9 @@
 #ifndef B2_DBG_STAMP
 #define B2_DBG_STAMP 0     // s_memtime stamps of one chunk (block 0, waves 0 and 4) into LDS, dumped over the first bytes of `out`
 #endif
+#ifndef B2_EVEN_TILES
+#define B2_EVEN_TILES 0
+#endif
 #ifndef B2_DBG_NOREAD
 #define B2_DBG_NOREAD 0
 #endif
@@ -220,8 +223,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(Big2Args a) {
 
     // tile j of this workgroup: units [u_lo + nu_wg * j / ntile_wg, u_lo + nu_wg * (j + 1) / ntile_wg)
     auto tile_units = [&](int j, int& t_u0, int& t_nu) __attribute__((always_inline)) {
+#if B2_EVEN_TILES
         t_u0 = u_lo + nu_wg * j / ntile_wg;
         t_nu = u_lo + nu_wg * (j + 1) / ntile_wg - t_u0;
+#else
+        // full tiles first, the remainder last: a half-step costs its LDS reads and barriers whatever the tile height,
+        // so 256 + 144 rows beat 200 + 200
+        t_u0 = u_lo + 16 * j;
+        t_nu = min(16, u_hi - t_u0);
+#endif
     };
 
     // bias of the lane's 16 channels, loaded once (an ordinary load inside the tile loop would make hipcc wait vmcnt(0)

@@ -191,9 +191,59 @@ def run_long_case(name, cfg, seed, dur_bias, Tp, dur_w_scale):
     print("%-28s Tp=%d frames=%d margin=%.2e max dur %d" % (name, Tp, T, margin, int(d.max())))
 
 
+def run_durations_case(name, utts, note):
+    """Durations of a whole BASELINE workload from the reference itself (encoder + duration predictor per utterance, the
+    path of network/fastspeech2.py:197-205 and network/variance_adaptor.py:117-138 with repairs D3-D6): per phone the
+    log-domain predictor output (fp32) and the rounded duration, per utterance the frame count.  The utterances are
+    regenerated by fastspeech2_amd.synth (numpy PCG64), the weights by synth.bench_state_dict(); nothing else is
+    stored.  A phone's rounding margin = distance of exp(logd) - 1 from the nearest .5 edge, derivable from logd."""
+    kw = dict(synth.BASELINE_OVERRIDES)
+    ns = ref_harness.load()
+    model = ns.FeedForwardTransformer(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.bench_state_dict().items()}, strict=True)
+    model.eval()
+    logds, durs, frames = [], [], []
+    with torch.no_grad():
+        for x in utts:
+            xt = torch.from_numpy(x)
+            ilens = torch.LongTensor([xt.shape[0]])
+            hs, _ = model.encoder.forward(xt.unsqueeze(0), model._source_mask(ilens))
+            va = model.variance_adaptor
+            logds.append(va.duration_predictor.forward(hs, None)[0].numpy().astype(np.float32))
+            d = va.duration_predictor.inference(hs, None)[0].numpy().astype(np.int64)
+            durs.append(d)
+            frames.append(int(d.sum()))
+    logd, dur = np.concatenate(logds), np.concatenate(durs)
+    assert dur.max() < 32767 and dur.min() >= 0
+    frac = np.exp(logd.astype(np.float64)) - 1.0
+    margin = np.abs(frac - np.floor(frac) - 0.5)
+    meta = dict(name=name, note=note, n=len(utts), phones=int(dur.size), frames=int(sum(frames)), torch=torch.__version__,
+                min_margin=float(margin.min()), below_1e5=int((margin < 1e-5).sum()), below_1e4=int((margin < 1e-4).sum()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=np.array(json.dumps(meta)), logd=logd,
+                        dur=dur.astype(np.int16), frames=np.array(frames, np.int32),
+                        ilens=np.array([len(x) for x in utts], np.int32))
+    print("%-28s n=%d phones=%d frames=%d min margin %.2e, phones with margin < 1e-5: %d, < 1e-4: %d"
+          % (name, len(utts), dur.size, sum(frames), margin.min(), meta["below_1e5"], meta["below_1e4"]))
+
+
+def durations_cases(only=None):
+    if not only or "durations_bench32" in only:
+        run_durations_case("durations_bench32", synth.synth_utterances(32, 0, idim=synth.BENCH_IDIM),
+                           "BASELINE config 2: the 32 utterances of bench.py (synth.synth_utterances(32, 0), length-sorted)")
+    if not only or "durations_config3_256" in only:
+        run_durations_case("durations_config3_256", synth.synth_utterances(256, 0, idim=synth.BENCH_IDIM, sort=False),
+                           "BASELINE config 3: the 256 utterances of bench.py --scaling strong "
+                           "(synth.synth_utterances(256, 0, sort=False))")
+
+
 def main():
     torch.set_num_threads(8)
     only = set(sys.argv[1:])
+    if only & {"durations_bench32", "durations_config3_256"}:
+        durations_cases(only)
+        only -= {"durations_bench32", "durations_config3_256"}
+        if not only:
+            return
     if only:            # python tests/golden/make_golden.py long_512 train_baseline_b32 : just these (new) fixtures
         if "long_512" in only:
             run_long_case("long_512", BASELINE, 1234, math.log(8.8), 512, 0.15)
@@ -226,6 +276,7 @@ def main():
     run_train_case("train_tiny_conv3_mixed", TINY_C, 13, math.log(5.0), B=2, Tp=10, alpha=1.1)
     run_long_case("long_512", BASELINE, 1234, math.log(8.8), 512, 0.15)
     run_train_case("train_baseline_b32", BASELINE, 1234, math.log(7.67), B=32, Tp=120, ds_lo=1, ds_hi=13, store_inputs=False)
+    durations_cases()
 
 
 if __name__ == "__main__":

@@ -242,6 +242,39 @@ def test_f16x3_encoder_durations_equal_the_fp32_engine_on_the_bench_batch():
     assert worst <= 5e-6, worst          # fp32 summation-order noise level (measured 1e-6; bf16 encoder: 4e-3)
 
 
+@pytest.mark.parametrize("precision", [("fp32", None), ("bf16", "f16x3")])
+@pytest.mark.parametrize("name", sorted(helpers.DURATION_CASES))
+def test_durations_of_the_full_workloads_equal_the_reference(name, precision):
+    """BASELINE config 2 (bench.py's 32 utterances, 3 767 phones) and config 3 (256 utterances, 30 727 phones, as eight
+    batches of 32): the durations the HIP path predicts against the REFERENCE's own, phone by phone (fixtures from
+    tests/golden/make_golden.py:run_durations_case), in the exact-fp32 mode and in the bench's headline mode (bf16
+    frame level, f16x3 phone level).  Equal on every phone whose rounding margin exceeds MARGIN_FLOOR; the phones below
+    it are counted and may differ by one frame at most."""
+    from fastspeech2_amd import synth
+    utts, logd_ref, dur_ref, margin, frames_ref, meta = helpers.duration_case(name)
+    kw = dict(synth.BASELINE_OVERRIDES)
+    model = FeedForwardTransformer(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.bench_state_dict().items()})
+    model.eval().cuda().set_precision(*precision)
+    dur, logd, frames = [], [], []
+    for b0 in range(0, len(utts), 32):
+        pk = model.infer_batch([torch.from_numpy(x) for x in utts[b0:b0 + 32]])["packed"]
+        dur.append(pk["durations_pred"].cpu().numpy().astype(np.int64))
+        logd.append(pk["log_durations"].cpu().numpy())
+        frames += [int(v) for v in pk["olens"]]
+    dur, logd = np.concatenate(dur), np.concatenate(logd)
+    assert dur.shape == dur_ref.shape
+    safe = margin > helpers.MARGIN_FLOOR
+    differing = int((dur != dur_ref).sum())
+    print("%s %s: %d phones, %d below the margin floor, %d durations differ, max |logd - ref| %.2e"
+          % (name, precision, dur.size, int((~safe).sum()), differing, np.abs(logd - logd_ref).max()))
+    assert np.array_equal(dur[safe], dur_ref[safe])
+    assert np.abs(dur - dur_ref).max() <= 1
+    assert np.abs(logd - logd_ref).max() <= 2e-5
+    if differing == 0:
+        assert frames == frames_ref.tolist()
+
+
 @pytest.mark.parametrize("name", helpers.TRAIN_CASES)
 def test_training_forward_loss_matches_reference(name):
     z, meta = helpers.load_golden(name)
