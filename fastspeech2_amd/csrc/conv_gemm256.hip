@@ -519,8 +519,14 @@ __global__ void pack_weight_tiled_kernel(const bf16_t* __restrict__ src, uint4* 
 
 // ---- host side ------------------------------------------------------------------------------------------------
 
-// 0: the shape is not served by the 256 x 256 kernel; else the number of K ranges (partial outputs) it will use when
-// the caller allows split-K (`want_split` != 0: an fs2_add_layernorm call sums the fp32 partials), 1 otherwise.
+// 0: the 256 x 256 kernel does not serve the shape, or fs2_conv_gemm is the faster one for it; else the number of K ranges
+// (partial outputs) it will use when the caller allows split-K (`want_split` != 0: an fs2_add_layernorm call sums the
+// fp32 partials), 1 otherwise.
+// A half-step of this kernel costs its LDS reads and two barriers whatever the tile height, so it wins only where the
+// rows of a workgroup fill whole 256-row tiles: measured against fs2_conv_gemm over M = 12 k .. 51 k tokens
+// (tools/conv256_sweep.py, both FFN conv shapes): 0.86-0.94 of its time where the last tile of a workgroup is >= 14 of
+// 16 units high (one tile per workgroup for 256 -> 1024 at M ~ 14-16 k; 1024 -> 256 at M ~ 28-33 k), 1.05-1.7 x
+// elsewhere.  M == 1 << 20 asks whether the shape is served at all (weight packing).
 extern "C" int fs2_conv_gemm256_plan(int M, int N, int Cin, int taps, int dtype, int want_split) {
     if (dtype != 1 || (taps != 9 && taps != 3)) return 0;
     if (N <= 0 || (N % 256) != 0 || Cin <= 0 || (Cin % 64) != 0) return 0;
@@ -534,6 +540,12 @@ extern "C" int fs2_conv_gemm256_plan(int M, int N, int Cin, int taps, int dtype,
         const int nchunks = Cin / 64;
         while (ks < 4 && n_tiles * ks * 2 <= 8 && nchunks / (ks * 2) >= 2 && (long long)M * n_tiles * ks < 192LL * 256) ks *= 2;
     }
+    if (M == (1 << 20)) return ks;
+    if (ks > 2) return 0;                                           // (four K ranges: not measured against fs2_conv_gemm)
+    const int groups = 256 / (n_tiles * ks);
+    const int units = ((M + 15) / 16 + groups - 1) / groups;        // 16-row units of the largest row group
+    const int last = units % 16;
+    if (units > 32 || (last != 0 && last < 14)) return 0;
     return ks;
 }
 

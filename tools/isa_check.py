@@ -1,0 +1,172 @@
+"""Static checks on the gfx950 code that ships in libfs2_gfx950.so (run by __graft_entry__.build() on the CPU box).
+
+The library's device code is pulled out of the .so (clang offload bundles in .hip_fatbin), disassembled with
+llvm-objdump and checked for the hazards that rounds 2 and 3 ran into:
+
+ (a) no packed-fp32 VALU instruction (v_pk_*_f32) reads an SGPR that a v_readlane / v_readfirstlane wrote fewer than
+     READLANE_WINDOW instructions earlier.  hipcc's SLP vectoriser emitted `v_pk_mul_f32 v[64:65], v[80:81], s[14:15]`
+     for layernorm_bwd's per-row scalars three instructions behind the `v_readlane_b32 s15` that produced half of the
+     pair, and rows came out wrong beside another kernel's bf16 MFMAs; the library is built with -fno-slp-vectorize, and
+     this check is what notices if another pass, another flag set or hand-written float2 code brings the pattern back.
+     (Packed instructions that read kernel-argument SGPRs - epilogue scales - are everywhere and are not this pattern.)
+ (b) every loop that both issues an LDS-DMA (global_load_lds_* / buffer_load_* ... lds) and reads LDS (ds_read_*)
+     contains an s_waitcnt with a vmcnt field followed by an s_barrier: the pair that orders a DMA's bytes in front of
+     other waves' reads.  (attention32_kernel once had its only vmcnt wait hoisted in front of the tile loop: no test
+     failed, single utterances differed from run to run.)
+ (c) no kernel that loads asynchronously from inline asm (results land in registers the compiler considers written) or
+     that counts its vmcnt by hand uses scratch memory: a spill or reload between the load and its wait would save or
+     restore stale registers.  Other kernels' scratch is reported.
+
+    python tools/isa_check.py [path/to/libfs2_gfx950.so]        # exit status 1 on a finding
+"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+# kernels whose source waits for asynchronous loads by hand (inline-asm ds_read_b64_tr_b16, counted vmcnt)
+NO_SCRATCH = ("attention32_kernel", "conv_gemm256_kernel", "conv_wgrad_kernelIDF16b", "attn_bwd_dq_kernelIDF16b",
+              "attn_bwd_dkv_kernelIDF16b")
+READLANE_WINDOW = 8
+
+
+def code_objects(lib, tmp):
+    fat = os.path.join(tmp, "fat.bin")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib])
+    data = open(fat, "rb").read()
+    out, pos = [], 0
+    while True:
+        i = data.find(MAGIC, pos)
+        if i < 0:
+            break
+        num = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(num):
+            o, s, t = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + t].decode()
+            off += t
+            if "gfx950" in triple and s > 0:
+                path = os.path.join(tmp, "co_%d.elf" % len(out))
+                open(path, "wb").write(data[i + o:i + o + s])
+                out.append(path)
+        pos = i + 24
+    return out
+
+
+INSN = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-F]+):\s*([0-9A-F]{8})")
+FUNC = re.compile(r"^[0-9a-f]+ <(\S+)>:")
+
+
+def functions(co):
+    """name -> list of (address, mnemonic, operands, first encoding word)"""
+    txt = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+    funcs, cur = {}, None
+    for line in txt.splitlines():
+        m = FUNC.match(line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        m = INSN.match(line)
+        if m and cur is not None:
+            cur.append((int(m.group(3), 16), m.group(1), m.group(2), int(m.group(4), 16)))
+    return funcs
+
+
+def metadata(co):
+    """kernel name -> (scratch bytes per lane, vgpr spill count)"""
+    txt = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    out, name, scratch = {}, None, 0
+    for line in txt.splitlines():
+        line = line.strip()
+        if line.startswith(".name:"):
+            name = line.split(":", 1)[1].strip()
+        elif line.startswith(".private_segment_fixed_size:"):
+            scratch = int(line.split(":", 1)[1])
+        elif line.startswith(".vgpr_spill_count:") and name is not None:
+            out[name] = (scratch, int(line.split(":", 1)[1]))
+    return out
+
+
+def is_dma(mn, ops):
+    return mn.startswith("global_load_lds") or (mn.startswith("buffer_load") and re.search(r"\blds\b", ops) is not None)
+
+
+def check_function(name, insns, findings):
+    # (a) packed fp32 arithmetic reading an SGPR fresh from a v_readlane / v_readfirstlane
+    fresh = []          # (instruction index, sgpr number)
+    for k, (addr, mn, ops, _) in enumerate(insns):
+        if mn.startswith("v_readlane") or mn.startswith("v_readfirstlane"):
+            m = re.match(r"\s*s(\d+)", ops)
+            if m:
+                fresh.append((k, int(m.group(1))))
+        if mn.startswith("v_pk_") and mn.endswith("_f32"):
+            regs = set()
+            for src in re.split(r",(?![^\[]*\])", ops)[1:]:          # (commas outside [lo:hi])
+                m = re.match(r"\s*s\[(\d+):(\d+)\]", src)
+                if m:
+                    regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                m = re.match(r"\s*s(\d+)\b", src)
+                if m:
+                    regs.add(int(m.group(1)))
+            for kk, r in fresh:
+                if r in regs and k - kk <= READLANE_WINDOW:
+                    findings.append("%s: %s %s at %#x reads s%d, written by a readlane %d instructions earlier"
+                                    % (name, mn, ops, addr, r, k - kk))
+            fresh = [(kk, r) for kk, r in fresh if k - kk <= READLANE_WINDOW]
+    # (b) loops (backward branches) with LDS-DMA and LDS reads need a vmcnt wait followed by a barrier inside
+    index = {a: k for k, (a, _, _, _) in enumerate(insns)}
+    for k, (addr, mn, ops, word) in enumerate(insns):
+        if not (mn.startswith("s_cbranch") or mn == "s_branch"):
+            continue
+        simm = word & 0xFFFF
+        simm = simm - 0x10000 if simm & 0x8000 else simm
+        target = addr + 4 + 4 * simm
+        if target > addr or target not in index:
+            continue
+        body = insns[index[target]:k + 1]
+        if not any(is_dma(m, o) for _, m, o, _ in body) or not any(m.startswith("ds_read") for _, m, _, _ in body):
+            continue
+        ok = False
+        waited = False
+        for _, m, o, _ in body:
+            if m == "s_waitcnt" and "vmcnt" in o:
+                waited = True
+            elif m == "s_barrier" and waited:
+                ok = True
+                break
+        if not ok:
+            findings.append("%s: the loop %#x..%#x issues LDS-DMA and reads LDS but holds no `s_waitcnt vmcnt` + `s_barrier` pair"
+                            % (name, target, addr))
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "fastspeech2_amd", "csrc", "libfs2_gfx950.so")
+    findings, notes = [], []
+    nfun = npk = ndma = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in code_objects(lib, tmp):
+            for name, insns in functions(co).items():
+                nfun += 1
+                npk += sum(1 for _, m, _, _ in insns if m.startswith("v_pk_") and m.endswith("_f32"))
+                ndma += 1 if any(is_dma(m, o) for _, m, o, _ in insns) else 0
+                check_function(name, insns, findings)
+            for name, (scratch, spills) in metadata(co).items():
+                if scratch or spills:
+                    msg = "%s: %d bytes of scratch per lane, %d spilled VGPRs" % (name, scratch, spills)
+                    (findings if any(k in name for k in NO_SCRATCH) else notes).append(msg)
+    print("isa_check: %d kernels, %d of them with LDS-DMA, %d packed-fp32 instructions" % (nfun, ndma, npk))
+    for n in notes:
+        print("  note: " + n)
+    for f in findings:
+        print("  FAIL: " + f)
+    return 1 if findings else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
