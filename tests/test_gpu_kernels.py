@@ -441,7 +441,8 @@ def test_attention(dtype, h, dk, lens):
     ctx = torch.empty((M, d), device=DEV, dtype=tdt)
     call("fs2_attention", ptr(qd), ptr(ctx), ptr(cu_d), len(lens), max(lens), h, dk, 3 * d, d, code, stream())
     err = (ctx.float().cpu().double() - ref).abs().max().item()
-    assert err <= (2e-5 if dtype == "fp32" else 3e-2), err
+    print("attention %s lens %s: max-abs err %.3g" % (dtype, lens[:4], err))
+    assert err <= (2e-5 if dtype == "fp32" else 1.5e-2), err       # bf16: 2 x the measured 5.8e-3..7.8e-3
     # debug dump of the softmax matrix (calculate_all_attentions)
     L0 = lens[0]
     att = torch.empty((h, L0, L0), device=DEV)

@@ -15,8 +15,8 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 
 FP32_MEL_TOL = 1e-3       # north_star
-BF16_MEL_TOL = 0.1        # max-abs on mel values of |.|max ~3.5; bf16 operands (8-bit mantissa) through the blocks
-BF16_MEL_RMS_TOL = 0.02   # measured: max 2e-2..4e-2, rms 6e-3..8e-3 (tools/diag_bf16.py)
+BF16_MEL_TOL = 0.05       # max-abs on mel values of |.|max ~3.5; bf16 operands (8-bit mantissa) through the blocks; measured 1.3e-2..3.8e-2 on the fixtures
+BF16_MEL_RMS_TOL = 0.012  # measured rms 4e-3..7.8e-3: a 2 x accuracy regression fails either this or the max-abs bar
 
 
 def build_model(meta, precision="fp32", encoder_dtype=None):
@@ -78,6 +78,7 @@ def test_bf16_teacher_forced_durations(name):
         mel = out["mel"].cpu().numpy()
         ref = z["mel_%d" % i]
         assert mel.shape == ref.shape
+        print("bf16 %s utt %d: mel max-abs err %.3g, rms %.3g" % (name, i, np.abs(mel - ref).max(), np.sqrt(np.mean((mel - ref) ** 2))))
         assert np.abs(mel - ref).max() <= BF16_MEL_TOL
         assert np.sqrt(np.mean((mel - ref) ** 2)) <= BF16_MEL_RMS_TOL
 
@@ -128,6 +129,8 @@ def test_long_utterance_config4(name):
     out = eng.forward(ids.cuda(), [512], ds=ds)
     mel = out["mel"].cpu().numpy()
     assert mel.shape[0] == T
+    print("bf16 %s: mel max-abs err %.3g, rms %.3g" % (name, np.abs(mel[rows] - z["mel_rows_0"]).max(),
+                                                       np.sqrt(np.mean((mel[rows] - z["mel_rows_0"]) ** 2))))
     assert np.abs(mel[rows] - z["mel_rows_0"]).max() <= BF16_MEL_TOL
     assert np.sqrt(np.mean((mel[rows] - z["mel_rows_0"]) ** 2)) <= BF16_MEL_RMS_TOL
     assert np.array_equal(out["lr_index"].cpu().numpy(), idx)
