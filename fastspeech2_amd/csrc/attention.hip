@@ -662,12 +662,12 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
     constexpr int lds = 2 * 2 * AT_BK * DK * (int)sizeof(T);
     static unsigned long long lds_ok = 0;
     fs2_allow_lds((const void*)attention_kernel<T, DK, QT, OT>, lds, &lds_ok);
-    static const int xcd_on = getenv("FS2_ATTN_XCD") ? atoi(getenv("FS2_ATTN_XCD")) : 1;   // 0: plain grid (A/B runs)
+    static const int xcd_on = FS2_ENV_INT("FS2_ATTN_XCD", 1);   // 0: plain grid (A/B runs)
     AttnArgs aa = a;
     const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 64 * QT - 1) / (64 * QT), H, B, xcd_on != 0);
     if constexpr (sizeof(T) == 2) {
-        static const int v1 = getenv("FS2_ATTN_V1") ? atoi(getenv("FS2_ATTN_V1")) : 0;   // 1: the 16x16x32 kernel (A/B runs)
-        static const int groups = getenv("FS2_ATTN_GROUPS") ? atoi(getenv("FS2_ATTN_GROUPS")) : 0;   // 1 / 2: forced
+        static const int v1 = FS2_ENV_INT("FS2_ATTN_V1", 0);   // 1: the 16x16x32 kernel (A/B runs)
+        static const int groups = FS2_ENV_INT("FS2_ATTN_GROUPS", 0);   // 1 / 2: forced
         if (!v1) {
             // two key groups per workgroup when one-group workgroups would leave CUs empty (measured: 66 workgroups,
             // config 4 B = 1, 86 -> 71 us; 264 or 448 workgroups are 10 % faster with one group, two per CU)
@@ -678,7 +678,7 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
             // the frame level it loses (config 2: 43.3 vs 39.8 us, uniform 64 x 1024: 644 vs 795-810 TFLOP/s: both forms
             // have every workgroup resident from the start, and 32-key trips pay the per-trip costs twice).
             // FS2_ATTN_Q64 = 0 / 1 forces (A/B runs).
-            static const int q64_env = getenv("FS2_ATTN_Q64") ? atoi(getenv("FS2_ATTN_Q64")) : -1;
+            static const int q64_env = FS2_ENV_INT("FS2_ATTN_Q64", -1);
             const bool q64 = !two && (q64_env >= 0 ? q64_env != 0 : max_len <= 4 * AT_BK);
             static unsigned long long ok[6] = {0, 0, 0, 0, 0, 0};
             const void* k;

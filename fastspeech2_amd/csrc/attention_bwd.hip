@@ -358,7 +358,7 @@ static int launch_attention_bwd(const AttnBwdArgs& a, int B, int H, int max_len,
     static unsigned long long ok_dq = 0, ok_dkv = 0;
     fs2_allow_lds((const void*)attn_bwd_dq_kernel<T, DK>, lds, &ok_dq);
     fs2_allow_lds((const void*)attn_bwd_dkv_kernel<T, DK>, lds_dkv, &ok_dkv);
-    static const int xcd_on = getenv("FS2_ATTN_XCD") ? atoi(getenv("FS2_ATTN_XCD")) : 1;   // 0: plain grid (A/B runs)
+    static const int xcd_on = FS2_ENV_INT("FS2_ATTN_XCD", 1);   // 0: plain grid (A/B runs)
     AttnBwdArgs aa = a;
     const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + AB_BT - 1) / AB_BT, H, B, xcd_on != 0);
     hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DK>), grid, dim3(AB_THREADS), lds, stream, aa);

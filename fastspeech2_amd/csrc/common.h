@@ -248,6 +248,17 @@ __device__ __forceinline__ bool fs2_pair_order_decode(const PairOrder& o, int& b
     return true;
 }
 
+// ---- experiment switches ------------------------------------------------------------------------------
+// The shipped library reads NO environment variables: FS2_ENV_INT(name, default) is the default.  A build made with
+// -DFS2_EXPERIMENT (tools/build_variant.sh TAG -DFS2_EXPERIMENT, used through FS2_LIB=variants/libfs2_TAG.so) reads the
+// named variable once per process instead - the A/B knobs the measurements in DESIGN.md were taken with.
+#ifdef FS2_EXPERIMENT
+#include <stdlib.h>
+#define FS2_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define FS2_ENV_INT(name, dflt) (dflt)
+#endif
+
 // ---- error codes of the C ABI (include/fs2_hip.h) -----------------------------------------
 #define FS2_OK 0
 #define FS2_ERR_ARG (-1)

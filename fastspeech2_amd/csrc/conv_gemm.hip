@@ -540,10 +540,10 @@ static int conv_gemm_plan_grid(ConvGemmArgs& a, int BM, int BN, size_t elem) {
     a.m_tiles = m_tiles;
     int grid_x = a.n_tiles * m_tiles;
     a.xcd_sets = a.xcd_group = 0;
-    static const int krot = getenv("FS2_CONV_KROT") ? atoi(getenv("FS2_CONV_KROT")) : 1;   // 0: off (A/B runs)
+    static const int krot = FS2_ENV_INT("FS2_CONV_KROT", 1);   // 0: off (A/B runs)
     a.krot = krot;
     // N tiles whose W slices (all taps) fit ~2.5 MB of an XCD's L2 form a group; sets = n_tiles / group
-    static const int xcd_on = getenv("FS2_CONV_XCD") ? atoi(getenv("FS2_CONV_XCD")) : 1;
+    static const int xcd_on = FS2_ENV_INT("FS2_CONV_XCD", 1);
     const double slice = (double)a.taps * BN * a.Cin * elem;     // all K ranges of a split are resident together
     int group = (int)(2.5e6 / slice);
     if (xcd_on && group >= 2 && a.n_tiles >= 2 && m_tiles >= 64) {
@@ -577,7 +577,7 @@ static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
 // Used by the phone-level half only (a few thousand tokens): 64 x 64 tiles when 128 x 128 would leave CUs idle.
 static int dispatch_conv_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
-    static const int forced = getenv("FS2_SPLIT_TILE") ? atoi(getenv("FS2_SPLIT_TILE")) : 0;   // experiments: 22, 24, 42, 44
+    static const int forced = FS2_ENV_INT("FS2_SPLIT_TILE", 0);   // experiments: 22, 24, 42, 44
     if (forced == 22) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
     if (forced == 24) return launch_conv_gemm<float, 2, 4, 2, 1, false, 3, 0, true>(a, stream);
     if (forced == 42) return launch_conv_gemm<float, 4, 2, 2, 1, false, 3, 0, true>(a, stream);
@@ -616,7 +616,7 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // And for the decoder convs: W ring of three (two steps ahead, counted waits) + single X image = 65 KB, two
     // workgroups per CU: 87.7 vs 83.8 us per launch — three workgroups with one stage ahead hide more than two with two.
     // FS2_CONV_MT=2|3|4 forces a tile height (experiments).
-    static const int forced = getenv("FS2_CONV_MT") ? atoi(getenv("FS2_CONV_MT")) : 0;
+    static const int forced = FS2_ENV_INT("FS2_CONV_MT", 0);
     // (only while the 96-row tiling itself still fits one round of 768 resident workgroups: M = 21000 with two K
     // ranges is 660 tiles of 128 rows but 876 of 96, whose short second round cost 120 vs 105 us)
     const long blocks96 = (long)((a.M + 95) / 96) * ((a.N + 127) / 128) * a.ksplit;
@@ -625,7 +625,7 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     // give the CUs more workgroups to hide the stage latency with.  First FFN conv (N = 1024, K = 2304) alone, us per
     // launch with 128 / 96 / 64 rows: M = 3767 (240 tiles): 36.9 / 36.8 / 31.8; 6144 (384): 45.6 / 39.1 / 38.4;
     // 9216 (576): 53.7 / 48.6 / 60.5; 12383 (776): 72.7 / 70.5 / 79.4; from 15000 (944) up 128 rows win or tie.
-    static const int low_tiles = getenv("FS2_CONV_LOWTILES") ? atoi(getenv("FS2_CONV_LOWTILES")) : 1;   // 0: off (A/B runs)
+    static const int low_tiles = FS2_ENV_INT("FS2_CONV_LOWTILES", 1);   // 0: off (A/B runs)
     if (low_tiles && a.ksplit == 1 && a.N > 256 && a.Cin * a.taps >= 1024) {
         // (64 rows below 320 tiles: -14 % for that launch alone, but in the bench's overlapped mode, where the phone-level
         // convs run beside the frame-level ones, the step got 1 % slower; not used)

@@ -737,7 +737,7 @@ static int add_layernorm_entry(const float* x, const float* parts, int nparts, l
         // 19.5 / 28.0 us at 24.7 k x 256 with 1 / 3 partials: the kernel moves 72-78 % of the copy rate either way); beside
         // the GEMMs of the other streams in the throughput loop it is: bench.py A/B/A/B/A/B 1.827-1.830 -> 1.808-1.826 ms
         // per step (exact mode), 1.660-1.678 -> 1.633-1.653 (pure bf16).  FS2_LN_ROWS4=0: the one-row form.
-        static const int rows4 = getenv("FS2_LN_ROWS4") ? atoi(getenv("FS2_LN_ROWS4")) : 1;
+        static const int rows4 = FS2_ENV_INT("FS2_LN_ROWS4", 1);
         const bool fast = rows4 && w && !dparts.thresh && !dout.thresh && (C == 256 || C == 384) && M >= 1024;
         const dim3 g4(blocks_for((M + 3) / 4, 4));
         if (fast && C == 256)
@@ -819,6 +819,28 @@ extern "C" int fs2_lr_plan(const int* dur_in, const int* cu_phone, float control
     hipLaunchKernelGGL(lr_plan_kernel, dim3(1), dim3(1024), 0, stream, dur_in, cu_phone, control,
                        control != 1.0f ? 1 : 0, dur_out, cum, olens, cu_frames, B);
     FS2_CHECK_LAUNCH("fs2_lr_plan");
+    return FS2_OK;
+}
+
+// cu[0] = 0, cu[b + 1] = lens[0] + .. + lens[b]: the frame offsets of a sub-batch of a grouped phone phase, rebased to its own
+// first frame (one wave; replaces a device-side subtraction the host schedule used to issue through torch)
+__global__ __launch_bounds__(64) void cu_from_lens_kernel(const int* __restrict__ lens, int* __restrict__ cu, int n) {
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int b = base + lane;
+        const int v = b < n ? lens[b] : 0;
+        const int sc = wave_iscan(v, lane);
+        if (b < n) cu[b + 1] = carry + sc;
+        carry += __shfl(sc, 63, 64);
+    }
+    if (lane == 0) cu[0] = 0;
+}
+
+extern "C" int fs2_cu_from_lens(const int* lens, int* cu, int n, hipStream_t stream) {
+    FS2_CHECK_ARG(lens && cu && n > 0, "fs2_cu_from_lens: bad args");
+    hipLaunchKernelGGL(cu_from_lens_kernel, dim3(1), dim3(64), 0, stream, lens, cu, n);
+    FS2_CHECK_LAUNCH("fs2_cu_from_lens");
     return FS2_OK;
 }
 

@@ -207,11 +207,21 @@ class Engine:
         self.pitch_pred = _Predictor(sd, va + "pitch_predictor.", dev, self.dec_code)
         self.energy_pred = _Predictor(sd, va + "energy_predictor.", dev, self.dec_code)
         wp, we = g(va + "pitch_embed.conv.conv.weight"), g(va + "energy_embed.conv.conv.weight")
-        if wp.shape[-1] != 1 or we.shape[-1] != 1:
-            raise NotImplementedError("pitch/energy embed kernel size must be 1")
-        self.wp, self.bp = wp[:, :, 0].contiguous(), g(va + "pitch_embed.conv.conv.bias")
-        self.we, self.be = we[:, :, 0].contiguous(), g(va + "energy_embed.conv.conv.bias")
-        self.pdim, self.edim = self.wp.shape[1], self.we.shape[1]
+        self.bp, self.be = g(va + "pitch_embed.conv.conv.bias"), g(va + "energy_embed.conv.conv.bias")
+        self.pdim, self.edim = wp.shape[1], we.shape[1]
+        self.embed_taps = (int(wp.shape[-1]), int(we.shape[-1]))
+        if self.embed_taps == (1, 1):           # the reference default: both embeddings folded into the add kernel
+            self.wp, self.we = wp[:, :, 0].contiguous(), we[:, :, 0].contiguous()
+        else:
+            # pitch / energy_embed_kernel_size > 1 (network/variance_adaptor.py:35-51, any odd k): the embeddings are
+            # convs over time, run as fp32 fs2_conv_gemm launches over inputs padded to 4 channels (16-byte rows); the
+            # add kernel then runs with zero embedding weights over hs + both embeddings
+            if self.embed_taps[0] % 2 == 0 or self.embed_taps[1] % 2 == 0 or max(self.embed_taps) > 9:
+                raise NotImplementedError("pitch/energy embed kernel sizes must be odd and <= 9")
+            pad4 = lambda w: torch.nn.functional.pad(w, (0, 0, 0, (-w.shape[1]) % 4))
+            self.wp_conv, self.we_conv = pack_gemm_weight(pad4(wp), F32), pack_gemm_weight(pad4(we), F32)
+            self.wp, self.we = torch.zeros_like(wp[:, :, 0]).contiguous(), torch.zeros_like(we[:, :, 0]).contiguous()
+            self.zero_b = torch.zeros_like(self.bp)
         self.w_out = pack_gemm_weight(g("feat_out.weight"), self.dec_code)
         self.b_out = g("feat_out.bias")
         self.odim = self.b_out.shape[0] // self.r
@@ -228,8 +238,7 @@ class Engine:
                 w = w * scale.view(-1, 1, 1)
             self.postnet.append(dict(w=pack_gemm_weight(w, self.dec_code), b=bias.contiguous(), taps=w.shape[-1],
                                      cout=w.shape[0], cin=w.shape[1]))
-        import os
-        self.big_tiles = os.environ.get("FS2_BIG_TILES", "1") != "0"     # A/B switch of the 256 x 256 FFN-conv kernel
+        self.big_tiles = True          # fs2_conv_gemm256 where fs2_conv_gemm256_plan picks it (False: fs2_conv_gemm always)
         self._pe = None
         self.profile = None     # optional list collecting (tag, kind, work, start_event, end_event): bench.py rooflines
 
@@ -402,6 +411,25 @@ class Engine:
         call("fs2_rowdot", ptr(y32), ptr(pr.lin_w), ptr(pr.lin_b), ptr(out), M, cin, pr.nout, stream())
         return out
 
+    def _conv_embeddings(self, hs_lr32, p_in, e_in, pscale, escale, seg_f, Mf):
+        """hs + pitch_embed(p) + energy_embed(e) for embedding convs with kernel size > 1 (VarianceEmbedding / ConvNorm:
+        Conv1d over time with 'same' zero padding inside each utterance, network/variance_adaptor.py:35-51,
+        network/utils.py:22-36).  pitch_control / energy_control scale the predictor outputs before the embedding."""
+        d = self.d
+        emb = self._empty((2, Mf, d), dtype=torch.float32)
+        for j, (v, scale, w, b, taps) in enumerate(((p_in, pscale, self.wp_conv, self.bp, self.embed_taps[0]),
+                                                    (e_in, escale, self.we_conv, self.be, self.embed_taps[1]))):
+            c4 = w.shape[-1]
+            x4 = torch.zeros((Mf, c4), device=self.dev, dtype=torch.float32)
+            x4[:, :v.shape[1]].copy_(v)
+            if scale != 1.0:
+                call("fs2_scale", ptr(x4), float(scale), ptr(x4), Mf * c4, stream())
+            self._gemm(x4, w, b, Mf, d, c4, taps, F32, seg=seg_f if taps > 1 else None, out_f32=True, out=emb[j])
+        hs_in = self._empty((Mf, d), dtype=torch.float32)
+        call("fs2_add_layernorm", ptr(hs_lr32), ptr(emb), 2, Mf * d, None, None, ptr(hs_in), None, None, Mf, d, LN_EPS, F32,
+             stream())
+        return hs_in
+
     # ------------------------------------------------------------------ forward
     def forward(self, ids: torch.Tensor, ilens: Sequence[int], duration_control: float = 1.0,
                 ds: Optional[torch.Tensor] = None, ps: Optional[torch.Tensor] = None,
@@ -489,10 +517,9 @@ class Engine:
             ctx["done"].synchronize()
             cu_f = ctx["cu_host"].numpy()
         cu_phone, cu_frames, hs32, cum = ctx["cu_phone"], ctx["cu_frames"], ctx["hs32"], ctx["cum"]
-        if "cu_slice" in ctx:                   # one batch of a grouped phone phase: rebase the frame offsets
-            u0, u1 = ctx["cu_slice"]
+        if "cu_slice" in ctx:                   # one batch of a grouped phone phase: frame offsets rebased to its first frame
+            u0, u1 = ctx["cu_slice"]            # (host copy here; the device copy was made in the phone phase)
             cu_f = cu_f[u0:u1 + 1] - cu_f[u0]
-            cu_frames = cu_frames[u0:u1 + 1] - cu_frames[u0:u0 + 1]
         olens = np.diff(cu_f).astype(np.int64).tolist()
         Mf = int(cu_f[-1])
         max_ol = max(olens) if B else 0
@@ -520,10 +547,13 @@ class Engine:
         y32 = self._empty((Mf, d), dtype=torch.float32)
         yt = self._empty((Mf, d), dc) if (dec_post and dc != F32) else None
         # (the positional table rows are shared by all utterances and stay in L2: not counted as HBM bytes)
+        hs_in, bp, be = hs_lr32, self.bp, self.be
+        if self.embed_taps != (1, 1):
+            hs_in, bp, be = self._conv_embeddings(hs_lr32, p_in, e_in, pscale, escale, seg_f, Mf), self.zero_b, self.zero_b
         with self._timed("variance_add_posenc", "byte", Mf * (4.0 * d + 4.0 * (self.pdim + self.edim) + 4 + 4.0 * d +
                                                               (2.0 * d if yt is not None else 0.0))):
-            call("fs2_variance_add_posenc", ptr(hs_lr32), ptr(p_in), ptr(e_in), ptr(self.wp), ptr(self.bp), ptr(self.we),
-                 ptr(self.be), pscale, escale, ptr(pe), ptr(pos_f), self.dec_xscale, self.dec_alpha, None, ptr(y32),
+            call("fs2_variance_add_posenc", ptr(hs_in), ptr(p_in), ptr(e_in), ptr(self.wp), ptr(bp), ptr(self.we),
+                 ptr(be), pscale, escale, ptr(pe), ptr(pos_f), self.dec_xscale, self.dec_alpha, None, ptr(y32),
                  ptr(yt), Mf, d, self.pdim, self.edim, dc, stream())
         if dc == F32:
             yt = y32
@@ -598,8 +628,12 @@ class Engine:
                 if len(got) == 1:
                     pending.append(self.phone_phase(got[0][0], got[0][1], kw.get("duration_control", 1.0)))
                 else:
-                    ids = torch.cat([b[0] for b in got])
                     ilens = [int(v) for b in got for v in b[1]]
+                    ids = torch.empty((sum(ilens),), dtype=torch.int64, device=self.dev)
+                    o = 0
+                    for b in got:                       # device-to-device copies into one ragged batch
+                        ids[o:o + b[0].numel()].copy_(b[0], non_blocking=True)
+                        o += b[0].numel()
                     ctx = self.phone_phase(ids, ilens, kw.get("duration_control", 1.0))
                     u0 = p0 = 0
                     subs = []
@@ -647,7 +681,10 @@ class Engine:
         cu_p = np.zeros(len(il) + 1, np.int32)
         cu_p[1:] = np.cumsum(il)
         sub = dict(ctx)
+        cu_fr = torch.empty((u1 - u0 + 1,), dtype=torch.int32, device=ctx["hs32"].device)
+        call("fs2_cu_from_lens", ptr(ctx["keep"][2][u0:u1]), ptr(cu_fr), u1 - u0, stream())       # keep[2] = olens_dev
         sub.update(B=u1 - u0, Mp=p1 - p0, ilens=il, cu_phone=torch.from_numpy(cu_p).to(ctx["hs32"].device, non_blocking=True),
+                   cu_frames=cu_fr,
                    hs32=ctx["hs32"][p0:p1], cum=ctx["cum"][p0:p1], dur_used=ctx["dur_used"][p0:p1],
                    dur_pred=ctx["dur_pred"][p0:p1], logd=ctx["logd"][p0:p1], cu_slice=(u0, u1),
                    enc_att=None if ctx["enc_att"] is None else [a[u0:u1] for a in ctx["enc_att"]])

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "fs2_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],
     "fs2_duration_round": [_P, _P, _I, _P],
     "fs2_lr_plan": [_P, _P, _F, _P, _P, _P, _P, _I, _P],
+    "fs2_cu_from_lens": [_P, _P, _I, _P],
     "fs2_lr_gather": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "fs2_variance_add_posenc": [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _F, _F, _P, _P, _P,
                                 _I, _I, _I, _I, _I, _P],

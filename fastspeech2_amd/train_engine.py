@@ -792,13 +792,23 @@ class TrainEngine:
             # nn.Dropout inside VarianceEmbedding (network/variance_adaptor.py:35-51; reference default 0): the two
             # embeddings are formed apart ([Mf, 4] x [4, d] and [Mf, 1] x [1, d]), dropped out and added to hs_lr; the
             # fused kernel then runs with zero embedding weights
-            ep = torch.addmm(b_pe, ps, w_pe.view(d, self.pdim).t())
-            ee = torch.addmm(b_ee, es, w_ee.view(d, self.edim).t())
+            # (each embedding alone = the fused kernel over a zero residual with the other embedding's weights zeroed and
+            # the positional term switched off; their sum with hs_lr = fs2_add_layernorm without a norm)
+            zw_p, zb_p, zw_e, zb_e = (torch.zeros_like(t) for t in (w_pe, b_pe, w_ee, b_ee))
+            zero_hs = torch.zeros((Mf, d), device=self.dev, dtype=torch.float32)
+            emb = self._empty((2, Mf, d), torch.float32)
+            ep, ee = emb[0], emb[1]
+            call("fs2_variance_add_posenc", ptr(zero_hs), ptr(ps), ptr(es), ptr(w_pe), ptr(b_pe), ptr(zw_e), ptr(zb_e), 1.0, 1.0,
+                 ptr(pe_f), ptr(pos_f), 1.0, 0.0, None, ptr(ep), None, Mf, d, self.pdim, self.edim, F32, stream())
+            call("fs2_variance_add_posenc", ptr(zero_hs), ptr(ps), ptr(es), ptr(zw_p), ptr(zb_p), ptr(w_ee), ptr(b_ee), 1.0, 1.0,
+                 ptr(pe_f), ptr(pos_f), 1.0, 0.0, None, ptr(ee), None, Mf, d, self.pdim, self.edim, F32, stream())
             if r_pe > 0.0:
                 call("fs2_dropout", ptr(ep), None, Mf, d, self.seed, self.SITE_PITCH_EMB, r_pe, F32, stream())
             if r_ee > 0.0:
                 call("fs2_dropout", ptr(ee), None, Mf, d, self.seed, self.SITE_ENERGY_EMB, r_ee, F32, stream())
-            hs_in = hs_lr32 + ep + ee
+            hs_in = self._empty((Mf, d), torch.float32)
+            call("fs2_add_layernorm", ptr(hs_lr32), ptr(emb), 2, Mf * d, None, None, ptr(hs_in), None, None, Mf, d, LN_EPS,
+                 F32, stream())
             w_pe, b_pe, w_ee, b_ee = (torch.zeros_like(t) for t in (w_pe, b_pe, w_ee, b_ee))
         vargs = (ptr(hs_in), ptr(ps), ptr(es), ptr(w_pe), ptr(b_pe), ptr(w_ee), ptr(b_ee), 1.0, 1.0, ptr(pe_f),
                  ptr(pos_f), xscale)

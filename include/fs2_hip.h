@@ -104,6 +104,26 @@ int fs2_conv_gemm_f16x3(const void* X, const void* W, float w_scale, const float
  * scale: a power of two that brings max |w| near 2^13 (the fp16 low halves then stay normal numbers). */
 int fs2_pack_weight_f16x3(const float* src, void* dst, int N, int C, int k, float scale, hipStream_t stream);
 
+/* fs2_conv_gemm for the big frame-level FFN convs (nn.Conv1d x 2 of MultiLayeredConv1d, network/encoder.py:16-30) on
+ * 256 x 256 tiles: one persistent 8-wave workgroup per CU, the W tile streamed through a ring of LDS half-stages by
+ * LDS-DMA from PRE-TILED weights (fs2_pack_weight_tiled), the two wave groups of a workgroup alternating between an MFMA
+ * segment and a load segment (csrc/conv_gemm256.hip).  bf16 only, taps 9 or 3, N % 256 == 0 (N / 256 in {1, 2, 4, 8}),
+ * Cin % 64 == 0, activation 0 / 1; same arguments, semantics and split-K convention as fs2_conv_gemm otherwise
+ * (N / 256 * ksplit must divide 8).  Same results as fs2_conv_gemm up to fp32 summation order. */
+int fs2_conv_gemm256(const void* X, const void* Wt, const float* bias, const float* res, void* out, const int* seg, int M,
+                     int N, int Cin, int taps, int ldx, int ldr, int ldo, int relu, int out_f32, int dtype, int ksplit,
+                     long long split_stride, hipStream_t stream);
+
+/* Weight operand of fs2_conv_gemm256 from fs2_conv_gemm's W [taps][N][Cin] (bf16): for every (256-channel tile, 64-channel
+ * chunk, tap, k half) one contiguous 16-KB block in the order of the kernel's LDS image (64-byte rows, 16-byte slots
+ * XOR-swizzled).  dst holds taps * N * Cin elements. */
+int fs2_pack_weight_tiled(const void* W, void* dst, int N, int Cin, int taps, int dtype, hipStream_t stream);
+
+/* 0 where fs2_conv_gemm is the kernel to use for this shape; else the `ksplit` to call fs2_conv_gemm256 with (1 unless
+ * want_split != 0, i.e. an fs2_add_layernorm call sums the partials).  M = 1 << 20 asks whether the shape is served at
+ * all (so that the caller packs tiled weights).  No launch; part of the kernel dispatch, no counterpart in the reference. */
+int fs2_conv_gemm256_plan(int M, int N, int Cin, int taps, int dtype, int want_split);
+
 /* Split-K factor (>= 1) the launch schedules pass as `ksplit` for a GEMM of this shape whose partial outputs
  * an fs2_add_layernorm call sums: 1 unless the tiling would leave most CUs idle.  No launch; no counterpart in
  * the reference (it is part of the kernel dispatch). */
@@ -143,6 +163,11 @@ int fs2_duration_round(const float* logd, int* dur, int M, hipStream_t stream);
  * `olens` and frame offsets `cu_frames` [B+1].  dur_out receives the durations actually used. */
 int fs2_lr_plan(const int* dur_in, const int* cu_phone, float control, int* dur_out, int* cum, int* olens,
                 int* cu_frames, int B, hipStream_t stream);
+
+/* cu[0] = 0, cu[b + 1] = lens[0] + .. + lens[b] (int32, n utterances): the frame offsets of a sub-batch rebased to its own
+ * first frame - the `olens` -> padded-batch bookkeeping of pad_list / make_pad_mask (network/utils.py:50-86) for one
+ * slice of a grouped phone phase. */
+int fs2_cu_from_lens(const int* lens, int* cu, int n, hipStream_t stream);
 
 /* LengthRegulator expansion + pad_list (network/variance_adaptor.py:31, network/utils.py:50-56) into
  * the packed frame matrix: out[f,:] = hs[cu_phone[b] + lr_index[f], :].  Also emits the frame-level
