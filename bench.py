@@ -33,7 +33,7 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fastspeech2_amd.run.launch import maybe_self_launch            # noqa: E402  (no torch, no GPU)
+from fastspeech2_amd.run.launch import bind_rank_cpus, maybe_self_launch   # noqa: E402  (no torch, no GPU)
 
 
 def _gpus_arg(argv):
@@ -47,6 +47,9 @@ def _gpus_arg(argv):
 
 if __name__ == "__main__":
     maybe_self_launch(_gpus_arg(sys.argv[1:]))     # N > 1 without a launcher: become N ranks (parent never touches a GPU)
+    CPU_SHARE = bind_rank_cpus()                   # a rank (under torchrun or self-launched): its share of the host cores
+else:
+    CPU_SHARE = None
 
 import numpy as np                                                   # noqa: E402
 import torch                                                         # noqa: E402
@@ -218,17 +221,18 @@ def main():
     fence()
     t0 = time.perf_counter()
     outs = run_steps(args.steps)
-    fence()
+    host_elapsed = time.perf_counter() - t0          # every launch of the timed steps enqueued (incl. the one blocking read
+    fence()                                          # of the frame counts per batch): ~ ms_per_step means host-bound
     elapsed = time.perf_counter() - t0
     frames = float(sum(sum(o["olens"]) for o in outs))
     flops = sum(synth.algorithmic_flops(l, o["olens"]) for (_, l), o in zip(feed, outs))
     phones = float(sum(sum(l) for _, l in feed))
-    stats = torch.tensor([elapsed, frames, flops, phones], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, frames, flops, phones, host_elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
+        elapsed, host_elapsed = float(mx[0]), float(mx[4])
         frames, flops, phones = float(stats[1]), float(stats[2]), float(stats[3])
 
     # ---- rooflines: HIP events on the launch stream around every tagged launch, one forward at a time (a second pass
@@ -339,10 +343,17 @@ def main():
                                     "frames), ") + "4+4 FFT blocks d=256 h=2 conv-k9 U=1024, random-init, idim=odim=80",
                        "frames_per_step": frames, "phones_per_step": phones, "batches_per_rank_and_step": len(feed),
                        "encoder_dtype": args.encoder_dtype,
-                       "durations": ("bit-exact vs the fp32 engine and the reference goldens (tests/test_gpu_model.py)"
+                       "durations": ("equal to the REFERENCE's on all 3 767 phones of this batch and all 30 727 of the 256-utterance "
+                                     "config-3 set (fixtures tests/golden/durations_*.npz generated by the reference itself; "
+                                     "tests/test_gpu_model.py::test_durations_of_the_full_workloads_equal_the_reference); exact "
+                                     "on the fixtures - a checkpoint whose activations leave the fp16 range is not covered"
                                      if args.encoder_dtype != "bf16" else "~1 % differ by one frame (bf16 encoder)"),
                        "pure_%s" % args.dtype: pure,
                        "step_overlap": "none" if args.serial else "phone-level halves of the next %d step(s) as one ragged batch on a side stream under the frame-level halves of the current ones; frame-level halves alternate over %d stream(s)" % (args.phone_group, args.frame_streams),
+                       "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4),
+                       "launch_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "phone_group": args.phone_group,
+                                      "frame_streams": args.frame_streams,
+                                      "cpus_of_rank0": None if CPU_SHARE is None else len(CPU_SHARE)},
                        "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
                        "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4)},

@@ -25,7 +25,7 @@ if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from fastspeech2_amd.run.launch import maybe_self_launch                 # noqa: E402  (no torch, no GPU)
+from fastspeech2_amd.run.launch import bind_rank_cpus, maybe_self_launch  # noqa: E402  (no torch, no GPU)
 
 if __name__ == "__main__":
     _n = 1
@@ -35,6 +35,9 @@ if __name__ == "__main__":
         elif _a.startswith("--gpus="):
             _n = int(_a.split("=", 1)[1])
     maybe_self_launch(_n)          # N > 1 without a launcher: become N ranks (the parent never touches a GPU)
+    CPU_SHARE = bind_rank_cpus()   # a rank (under torchrun or self-launched): its share of the host cores
+else:
+    CPU_SHARE = None
 
 import numpy as np                                                        # noqa: E402
 import torch                                                              # noqa: E402
@@ -138,15 +141,16 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         updater.update({"packed": packed})
+    host_elapsed = time.perf_counter() - t0           # every launch enqueued: ~ ms_per_step means the step is host-bound
     fence()
     elapsed = time.perf_counter() - t0
     loss = model.reporter.observation["loss"]
-    stats = torch.tensor([elapsed, frames], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, frames, host_elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        elapsed, frames = float(mx[0]), float(stats[1])
+        elapsed, frames, host_elapsed = float(mx[0]), float(stats[1]), float(mx[2])
 
     breakdown = None
     if rank == 0 and args.breakdown:
@@ -176,6 +180,9 @@ def main():
             "config": {"workload": "BASELINE config 5: 32 utterances/GPU, teacher-forced ds~randint(1,13), fwd + bwd + "
                                    "grad all-reduce (N>1) + clip + Adam(Noam); 4+4 FFT blocks d=256 h=2 conv-k9 U=1024",
                        "frames_per_step": frames, "params": nparams, "final_loss": round(loss, 5),
+                       "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4),
+                       "launch_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                                      "cpus_of_rank0": None if CPU_SHARE is None else len(CPU_SHARE)},
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),
                        "model_mfma_frac": round(flops * args.steps / elapsed / 1e12 / world / PEAK_TFLOPS[args.dtype], 4),
                        "dropout": "off" if args.no_dropout else

@@ -21,6 +21,29 @@ def _free_port() -> int:
     return port
 
 
+def bind_rank_cpus():
+    """Gives this rank its share of the CPUs it is allowed to run on: the allowed set (os.sched_getaffinity, i.e. the
+    container's or the job's cpuset) is cut into LOCAL_WORLD_SIZE contiguous parts and rank LOCAL_RANK keeps part
+    LOCAL_RANK, so that eight ranks issuing launches from Python do not migrate over each other's cores (contiguous CPU
+    numbers share a socket / NUMA node on the usual enumerations).  Call before torch is imported: threads created later
+    inherit the mask.  A no-op for a single rank, without sched_setaffinity, or when a rank would get no CPU.
+    Returns the list of CPUs kept (None when nothing was changed)."""
+    try:
+        n = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        r = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+        if n <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("FS2_NO_CPU_BIND"):
+            return None
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // n
+        if per < 1 or not 0 <= r < n:
+            return None
+        mine = cpus[r * per:(r + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (OSError, ValueError):
+        return None
+
+
 def maybe_self_launch(n_ranks: int, argv=None) -> None:
     """Returns in a process that is (or does not need to be) a rank; otherwise runs the ranks and exits with 0 only if
     every rank did (a rank that fails takes the others down instead of leaving them in a barrier)."""

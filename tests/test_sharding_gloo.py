@@ -109,3 +109,25 @@ def test_bench_gpus_2_launches_two_ranks_by_itself(script):
     bad = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2", "--rendezvous-only"],
                          env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+def test_rank_cpu_binding_splits_the_allowed_cpus():
+    """run/launch.py:bind_rank_cpus: every rank keeps a disjoint, equal share of the CPUs the job may use (checked in
+    child processes, so that this process keeps its own mask)."""
+    import os
+    import subprocess
+    import sys
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        return
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from fastspeech2_amd.run.launch import bind_rank_cpus; import os; "
+            "mine = bind_rank_cpus(); print(sorted(os.sched_getaffinity(0)) == mine, mine)" % root)
+    shares = []
+    for r in range(2):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="2", RANK=str(r), WORLD_SIZE="2")
+        out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip()
+        ok, mine = out.split(" ", 1)
+        assert ok == "True", out
+        shares.append(set(eval(mine)))
+    assert shares[0] and shares[1] and not (shares[0] & shares[1])
+    assert len(shares[0]) == len(shares[1]) == len(os.sched_getaffinity(0)) // 2
