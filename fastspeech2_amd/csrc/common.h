@@ -118,7 +118,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_src<0x118, 0xF>(v, 0.f);     // row_shr:8   -> lane 15 of each row: the row's sum
     v += dpp_src<0x142, 0xA>(v, 0.f);     // row_bcast:15 into rows 1, 3
     v += dpp_src<0x143, 0xC>(v, 0.f);     // row_bcast:31 into rows 2, 3
+#if defined(FS2_WAVE_SUM_VGPR)            // experiment: the total handed on in a VGPR, no SGPR operand downstream
+    return __shfl(v, 63, 64);
+#elif defined(FS2_WAVE_SUM_NOP)           // experiment: wait states between the v_readlane and its first reader
+    const float r = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    asm volatile("s_nop 7" ::: "memory");
+    return r;
+#else
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#endif
 }
 // sum over the 16 lanes of a DPP row, result in all 16 (xor butterfly: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
 // row_mirror): four VALU steps for four independent rows of lanes at once

@@ -66,3 +66,46 @@ def test_training_step_repeats_are_bit_identical():
         assert torch.equal(runs[0][0], other[0])
         for k in runs[0][1]:
             assert torch.equal(runs[0][1][k], other[1][k]), k
+
+
+def test_layernorm_bwd_beside_bf16_conv_wgrad_is_bit_stable():
+    """Reduced tools/lnb_race.py: fs2_layernorm_bwd on one stream while fs2_conv_wgrad (bf16: its MFMAs are what the
+    effect needs) keeps the chip busy on another, same inputs every launch - every output must equal the first launch's
+    bit for bit.  A build with hipcc's SLP vectoriser on (fastspeech2_amd/build.py turns it off: DESIGN.md section 4.3)
+    gives 15-30 differing outputs in 400 launches here; the static side of the guard is tools/isa_check.py."""
+    import ctypes
+    from fastspeech2_amd import hip
+    from fastspeech2_amd.hip import call, ptr
+    dev, M, C, N = "cuda:0", 26976, 256, 768
+    g = torch.Generator(device=dev).manual_seed(0)
+    x, dy = torch.randn(M, C, device=dev, generator=g), torch.randn(M, C, device=dev, generator=g)
+    parts = torch.randn(1, M, C, device=dev, generator=g)
+    w = torch.randn(C, device=dev, generator=g)
+    lib = hip.load()
+    ws = torch.empty(lib.fs2_layernorm_bwd_workspace(M, C) // 4 + 4, device=dev)
+    gy = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    gx = torch.randn(M, C, device=dev, generator=g).to(torch.bfloat16)
+    gw, gb = torch.empty(N, C, device=dev), torch.empty(N, device=dev)
+    ks = 16
+    wws = torch.empty(lib.fs2_conv_wgrad_workspace(N, C, 1, ks) // 4 + 4, device=dev)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    first, differing = None, 0
+    outs = []
+    torch.cuda.synchronize()
+    for it in range(300):
+        for _ in range(3):
+            call("fs2_conv_wgrad", ptr(gy), ptr(gx), ptr(gw), ptr(gb), ptr(wws), None, M, N, C, 1, N, C, 1, ks, 1.0, 0,
+                 ctypes.c_void_p(sb.cuda_stream))
+        of = torch.empty(M, C, device=dev)
+        ot = torch.empty(M, C, device=dev, dtype=torch.bfloat16)
+        dw = torch.empty(2 * C, device=dev)
+        call("fs2_layernorm_bwd", ptr(x), ptr(dy), ptr(parts), 1, M * C, ptr(w), None, 0, ptr(of), ptr(ot), ptr(dw),
+             ctypes.c_void_p(dw.data_ptr() + 4 * C), ptr(ws), M, C, 1e-12, 0, 1, 7, 1, 0.0, 2, 0.0, ctypes.c_void_p(sa.cuda_stream))
+        outs.append((of, ot, dw))
+        if len(outs) == 60:                # compare in batches: bounded memory, launches stay back to back in between
+            torch.cuda.synchronize()
+            if first is None:
+                first = outs[0]
+            differing += sum(1 for o in outs for a, b in zip(o, first) if not torch.equal(a, b))
+            outs = []
+    assert differing == 0, "%d outputs of 300 launches differ from the first launch's" % differing

@@ -17,6 +17,12 @@ llvm-objdump and checked for the hazards that rounds 2 and 3 ran into (DESIGN.md
      that counts its vmcnt by hand uses scratch memory: a spill or reload between the load and its wait would save or
      restore stale registers.  Other kernels' scratch is reported.
 
+ (d) layernorm_bwd_kernel holds no v_pk_mul_f32 / v_pk_fma_f32.  Round 3's experiment: with the
+     SLP vectoriser on, its outputs still differed from launch to launch beside bf16 conv_wgrad when the reduction
+     results were handed on in VGPRs (no SGPR operand anywhere) or followed by 8 wait states, so (a) alone does not
+     describe the hazard; what the failing builds have and the shipped one has not are these packed forms in this kernel
+     (its 31 v_pk_add_f32 from float4 adds are in both).  tests/test_zy_determinism.py runs the dynamic check.
+
     python tools/isa_check.py [path/to/libfs2_gfx950.so]        # exit status 1 on a finding
 """
 import os
@@ -118,6 +124,11 @@ def check_function(name, insns, findings):
                     findings.append("%s: %s %s at %#x reads s%d, written by a readlane %d instructions earlier"
                                     % (name, mn, ops, addr, r, k - kk))
             fresh = [(kk, r) for kk, r in fresh if k - kk <= READLANE_WINDOW]
+    # (d) the packed forms only the SLP-vectorised layernorm_bwd has
+    if "layernorm_bwd_kernel" in name:
+        n = sum(1 for _, m, _, _ in insns if m in ("v_pk_mul_f32", "v_pk_fma_f32"))
+        if n:
+            findings.append("%s: %d v_pk_mul_f32 / v_pk_fma_f32 (the SLP-vectorised form that miscomputed beside bf16 MFMAs)" % (name, n))
     # (b) loops (backward branches) with LDS-DMA and LDS reads need a vmcnt wait followed by a barrier inside
     index = {a: k for k, (a, _, _, _) in enumerate(insns)}
     for k, (addr, mn, ops, word) in enumerate(insns):
