@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--phone-group", type=int, default=2,
                     help="run the phone-level half of this many consecutive steps as one ragged batch (Engine.forward_pipelined)")
     ap.add_argument("--no-pure", action="store_true", help="skip the extra timed loop with the phone-level half in --dtype")
+    ap.add_argument("--engine-set", action="append", default=[], metavar="NAME=0|1",
+                    help="set a kernel-dispatch switch of the engine (reg_w, big_tiles): A/B runs; recorded in the line")
     ap.add_argument("--cpu-passes", type=int, default=12)   # ~10-15 s of host CPU work
     ap.add_argument("--force-dist", action="store_true",
                     help="with one GPU: still create the nccl (RCCL) group and run the barrier / reductions")
@@ -183,6 +185,11 @@ def main():
 
     model, sd_np, kw = build_model(args.dtype, args.encoder_dtype, dev)
     eng = model.engine()
+    for kv in args.engine_set:
+        k, v = kv.split("=")
+        if not isinstance(getattr(eng, k, None), bool):
+            raise SystemExit("--engine-set: the engine has no switch %r" % k)
+        setattr(eng, k, bool(int(v)))
     strong = args.scaling == "strong"
     batches = rank_batches_strong(world, rank) if strong else [rank_batch(world, rank)]
     feed = [(torch.from_numpy(np.concatenate(b)).to(dev), [len(x) for x in b]) for b in batches]
@@ -352,7 +359,7 @@ def main():
                        "step_overlap": "none" if args.serial else "phone-level halves of the next %d step(s) as one ragged batch on a side stream under the frame-level halves of the current ones; frame-level halves alternate over %d stream(s)" % (args.phone_group, args.frame_streams),
                        "host_ms_per_step": round(host_elapsed / args.steps * 1e3, 4),
                        "launch_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "phone_group": args.phone_group,
-                                      "frame_streams": args.frame_streams,
+                                      "frame_streams": args.frame_streams, "engine_set": args.engine_set or None,
                                       "cpus_of_rank0": None if CPU_SHARE is None else len(CPU_SHARE)},
                        "rtf": round((elapsed / args.steps) / (frames * HOP_SECONDS), 8),
                        "model_tflops": round(flops * args.steps / elapsed / 1e12, 2),

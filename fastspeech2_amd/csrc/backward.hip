@@ -565,7 +565,7 @@ extern "C" int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S
 static __device__ __align__(256) unsigned char scratch[FS2_STATIC_SCRATCH_BYTES];
 static float* g_scratch_ptr[64];          // per device ordinal; written once, read with atomics
 
-static int static_scratch(float** out) {
+static int static_scratch(float** out, hipStream_t stream, bool resolving_allowed) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= 64) {
@@ -574,6 +574,14 @@ static int static_scratch(float** out) {
     }
     float* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
     if (!p) {
+        // the first resolution on a device is a runtime query (it may load the code object): not something to do inside
+        // a stream capture - callers that capture warm up with fs2_colreduce_static_init()
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (!resolving_allowed || (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)) {
+            fs2_set_error("fs2_colreduce_static: the scratch address of device %d is not resolved yet and the stream is "
+                          "capturing: call fs2_colreduce_static_init() on this device first", dev);
+            return FS2_ERR_HIP;
+        }
         void* sym = nullptr;
         e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !sym) {
@@ -589,6 +597,13 @@ static int static_scratch(float** out) {
 
 extern "C" long long fs2_colreduce_static_max_bytes(void) { return FS2_STATIC_SCRATCH_BYTES; }
 
+// Resolves the scratch array's address on the CURRENT device (once per device and process; idempotent).  After it,
+// fs2_colreduce_static on that device is launches only: no runtime query, no allocation - usable under stream capture.
+extern "C" int fs2_colreduce_static_init(void) {
+    float* ws = nullptr;
+    return static_scratch(&ws, nullptr, true);
+}
+
 extern "C" int fs2_colreduce_static(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
                                     const int* pos, float* out, int M, int C, float scale, int accumulate,
                                     hipStream_t stream) {
@@ -599,7 +614,7 @@ extern "C" int fs2_colreduce_static(const void* G, int g_dtype, int ldg, const f
                   "use fs2_colreduce with a caller workspace",
                   M, C, R, need, (long long)FS2_STATIC_SCRATCH_BYTES);
     float* ws = nullptr;
-    const int rc = static_scratch(&ws);
+    const int rc = static_scratch(&ws, stream, true);
     if (rc != FS2_OK) return rc;
     return colreduce_launch("fs2_colreduce_static", G, g_dtype, ldg, S, lds, R, pe, pos, out, ws, M, C, scale, accumulate,
                             stream);

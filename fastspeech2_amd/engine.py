@@ -238,6 +238,8 @@ class Engine:
                 w = w * scale.view(-1, 1, 1)
             self.postnet.append(dict(w=pack_gemm_weight(w, self.dec_code), b=bias.contiguous(), taps=w.shape[-1],
                                      cout=w.shape[0], cin=w.shape[1]))
+        self.reg_w = False             # True: fs2_gemm_regw for the q | k | v projection of big batches (21.3 vs 22.8 us alone,
+                                       # no difference in the overlapped step: bench.py --engine-set reg_w=1)
         self.big_tiles = True          # fs2_conv_gemm256 where fs2_conv_gemm256_plan picks it (False: fs2_conv_gemm always)
         self._pe = None
         self.profile = None     # optional list collecting (tag, kind, work, start_event, end_event): bench.py rooflines
@@ -300,7 +302,11 @@ class Engine:
         esz = 2.0 if code == hip.BF16 else 4.0
         nbytes = M * Cin * esz + taps * N * Cin * esz + ksplit * M * N * (4.0 if out_f32 else esz) + (M * N * 4.0 if res is not None else 0.0)
         with self._timed(tag, "flop", 2.0 * M * N * Cin * taps, nbytes):
-            if wscale is not None:          # split-fp16 operands (pack_gemm_weight / T copies of code F16X3)
+            if (wscale is None and taps == 1 and ksplit == 1 and out.dim() == 2 and self.reg_w and
+                    hip.load().fs2_gemm_regw_plan(int(M), int(N), int(Cin), int(code), int(res is not None), int(relu),
+                                                  int(out_f32))):
+                call("fs2_gemm_regw", ptr(x), ptr(w), ptr(bias), ptr(out), M, N, Cin, Cin, N, int(out_f32), code, stream())
+            elif wscale is not None:          # split-fp16 operands (pack_gemm_weight / T copies of code F16X3)
                 assert code == hip.F16X3 and int(relu) in (0, 1)
                 call("fs2_conv_gemm_f16x3", ptr(x), ptr(w), wscale, ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin,
                      taps, Cin, N, N, int(relu), int(out_f32), ksplit, M * N, stream())

@@ -124,6 +124,17 @@ int fs2_pack_weight_tiled(const void* W, void* dst, int N, int Cin, int taps, in
  * all (so that the caller packs tiled weights).  No launch; part of the kernel dispatch, no counterpart in the reference. */
 int fs2_conv_gemm256_plan(int M, int N, int Cin, int taps, int dtype, int want_split);
 
+/* out = X . W^T + bias for the short-K projections of the frame-level half - the fused q | k | v nn.Linear(d, d) x 3 of
+ * MultiHeadedAttention (network/encoder.py:57-59, :73-76) - with the WEIGHTS IN REGISTERS (csrc/gemm_regw.hip): a wave
+ * keeps its 64 output channels x all Cin = 256 input channels of W in VGPRs for the whole launch and the launch streams
+ * the token rows through LDS in 16-row pieces (persistent workgroups, balanced row ranges).
+ * X [M, ldx] bf16, W [N][256] bf16 (fs2_conv_gemm's layout for taps == 1), bias fp32 [N] or NULL, out [M, ldo] bf16
+ * (out_f32 == 0) or fp32; N a multiple of 256.  Same results as fs2_conv_gemm with taps == 1 up to fp32 summation
+ * order.  fs2_gemm_regw_plan: 1 where this kernel serves the shape and is the one to use, else 0 (no launch). */
+int fs2_gemm_regw(const void* X, const void* W, const float* bias, void* out, int M, int N, int Cin, int ldx, int ldo,
+                  int out_f32, int dtype, hipStream_t stream);
+int fs2_gemm_regw_plan(int M, int N, int Cin, int dtype, int has_res, int relu, int out_f32);
+
 /* Split-K factor (>= 1) the launch schedules pass as `ksplit` for a GEMM of this shape whose partial outputs
  * an fs2_add_layernorm call sums: 1 unless the tiling would leave most CUs idle.  No launch; no counterpart in
  * the reference (it is part of the kernel dispatch). */
@@ -296,6 +307,12 @@ int fs2_colreduce(const void* G, int g_dtype, int ldg, const float* S, int lds, 
  * summation order, bit-identical results to fs2_colreduce.  All calls on one GPU share that array: calls that
  * overlap on one GPU (different streams or threads) race — serialise them. */
 long long fs2_colreduce_static_max_bytes(void);
+/* Resolves the static scratch array's address on the current device (hipGetSymbolAddress; once per device and process,
+ * idempotent; returns 0 or FS2_ERR_HIP).  fs2_colreduce_static resolves it lazily on its first call per device, which
+ * is a runtime query: callers that capture HIP graphs, or that must not touch the runtime inside their loop, call this
+ * once per device beforehand - after it every fs2_colreduce_static call on that device is kernel launches only.
+ * No counterpart in the reference (part of the no-allocation entry point above). */
+int fs2_colreduce_static_init(void);
 int fs2_colreduce_static(const void* G, int g_dtype, int ldg, const float* S, int lds, int R, const float* pe,
                          const int* pos, float* out, int M, int C, float scale, int accumulate, hipStream_t stream);
 

@@ -504,3 +504,26 @@ def test_bad_arguments_are_rejected():
         call("fs2_conv_gemm", ptr(x), ptr(x), None, None, ptr(x), None, 8, 8, 12, 2, 12, 8, 8, 0, 1, 0, 1, 0, stream())
     with pytest.raises(hip.HipError):
         call("fs2_attention", ptr(x), ptr(x), ptr(x), 1, 8, 1, 48, 144, 48, 0, stream())
+
+
+@pytest.mark.parametrize("M,N,out_f32", [(25611, 768, 0), (8200, 256, 1), (12345, 512, 0), (16, 256, 0), (4099, 768, 1)])
+def test_gemm_regw_matches_fp64(M, N, out_f32):
+    """fs2_gemm_regw (weights in registers, rows streamed; csrc/gemm_regw.hip) against fp64 on the bf16 operands and
+    against fs2_conv_gemm (same MFMAs, other summation order): ragged tails of the persistent row partition included."""
+    g = torch.Generator().manual_seed(M + N)
+    K = 256
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / 16).to(torch.bfloat16)
+    b = torch.randn(N, generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    dt = torch.float32 if out_f32 else torch.bfloat16
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=dt)
+    old = torch.empty((M, N), device=DEV, dtype=dt)
+    call("fs2_gemm_regw", ptr(xd), ptr(wd), ptr(bd), ptr(out), M, N, K, K, N, out_f32, 1, stream())
+    call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), None, ptr(old), None, M, N, K, 1, K, N, N, 0, out_f32, 1, 1, M * N, stream())
+    torch.cuda.synchronize()
+    err = (out.float().cpu().double() - ref).abs().max().item()
+    assert err <= (2e-4 if out_f32 else 3e-2), err           # bf16 output rounding: 2^-9 of |out| <= ~6
+    assert (out.float() - old.float()).abs().max().item() <= (1e-4 if out_f32 else 6.25e-2)
+    assert not torch.isnan(out.float()).any()

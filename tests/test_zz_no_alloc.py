@@ -69,3 +69,33 @@ def test_static_scratch_rejects_oversize():
     out = torch.zeros((R, C), device=DEV)
     with pytest.raises(hip.HipError, match="static scratch"):
         call("fs2_colreduce_static", ptr(G), 0, C, ptr(G), R, R, None, None, ptr(out), M, C, 1.0, 0, stream())
+
+
+def test_static_colreduce_allocates_nothing_and_captures():
+    """After fs2_colreduce_static_init() a call is launches only: the device's free memory does not move across calls and
+    a call recorded into a HIP graph replays to the eager result."""
+    lib = hip.load()
+    assert lib.fs2_colreduce_static_init() == 0
+    g = torch.Generator().manual_seed(5)
+    M, C = 4096, 256
+    G = torch.randn(M, C, generator=g).to(DEV)
+    out = torch.empty((1, C), device=DEV)
+    want = torch.empty((1, C), device=DEV)
+    ws = torch.empty((max(int(lib.fs2_colreduce_workspace(M, C, 1)), 16),), dtype=torch.uint8, device=DEV)
+    call("fs2_colreduce", ptr(G), 0, C, None, 0, 1, None, None, ptr(want), ptr(ws), M, C, 1.0, 0, stream())
+    call("fs2_colreduce_static", ptr(G), 0, C, None, 0, 1, None, None, ptr(out), M, C, 1.0, 0, stream())
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        call("fs2_colreduce_static", ptr(G), 0, C, None, 0, 1, None, None, ptr(out), M, C, 1.0, 0, stream())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.equal(out, want)
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call("fs2_colreduce_static", ptr(G), 0, C, None, 0, 1, None, None, ptr(out), M, C, 1.0, 0, stream())
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)

@@ -10,5 +10,5 @@ timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_s
 timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $R/$out/pmc4 -- python3 $R/tools/k1_probe.py > $R/$out/pmc4.log 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $R/$out/pmc5 -- python3 $R/tools/k1_probe.py > $R/$out/pmc5.log 2>&1 || exit 1
 cd $R
-for p in pmc1 pmc2 pmc3 pmc4 pmc5; do python tools/pmc_summary.py $out/$p conv_gemm >> $out/pmc_summary_$K1_SHAPE.txt 2>&1; done
+for p in pmc1 pmc2 pmc3 pmc4 pmc5; do python tools/pmc_summary.py $out/$p ${3:-conv_gemm} >> $out/pmc_summary_$K1_SHAPE.txt 2>&1; done
 rm -rf $out/pmc1 $out/pmc2 $out/pmc3 $out/pmc4 $out/pmc5

@@ -33,3 +33,19 @@ for name, (N, K, taps, f32, has_res, ks) in SHAPES.items():
     nbytes = M * K * 2 + taps * N * K * 2 + M * N * (4 if f32 else 2) + (M * N * 4 if has_res else 0)
     print("%-9s M=%d N=%d K=%d x %d taps: %.1f us  %.0f TFLOP/s  %.0f GB/s of algorithmic bytes (%.1f MB)"
           % (name, M, N, K, taps, us, 2.0 * M * N * K * taps / us * 1e-6, nbytes / us * 1e-3, nbytes * 1e-6), flush=True)
+if not only or only == "qkv_regw":
+    N, K = 768, 256
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) / 16).to(torch.bfloat16)
+    b = torch.zeros(N, device=dev)
+    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    run = lambda: call("fs2_gemm_regw", ptr(x), ptr(w), ptr(b), ptr(out), M, N, K, K, N, 0, 1, stream())
+    for _ in range(5): run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    n = 12 if only else 50
+    for _ in range(n): run()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    nbytes = M * K * 2 + N * K * 2 + M * N * 2
+    print("qkv_regw  M=%d N=%d K=%d: %.1f us  %.0f TFLOP/s  %.0f GB/s of algorithmic bytes" % (M, N, K, us, 2.0 * M * N * K / us * 1e-6, nbytes / us * 1e-3), flush=True)
