@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="no cross-step overlap: one forward after the other")
     ap.add_argument("--frame-streams", type=int, default=3, help="alternate the frame-level halves over this many streams")
-    ap.add_argument("--phone-group", type=int, default=2,
+    ap.add_argument("--phone-group", type=int, default=4,
                     help="run the phone-level half of this many consecutive steps as one ragged batch (Engine.forward_pipelined)")
     ap.add_argument("--no-pure", action="store_true", help="skip the extra timed loop with the phone-level half in --dtype")
     ap.add_argument("--engine-set", action="append", default=[], metavar="NAME=0|1",
