@@ -625,6 +625,244 @@ __global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArg
     }
 }
 
+// ---- f16x3: q | k | v in split-fp16 storage, every product on the fp16 matrix pipe -----------------------------
+// The phone-level half in its f16x3 mode (dtype code 3): the QKV projection writes q | k | v in split-fp16 storage
+// (common.h: per 32-channel run 32 hi halves, then 32 lo halves; hi + lo carries 22 of fp32's 24 significant bits) and
+// this kernel forms both products of the attention as three fp16 MFMAs each,
+//   S^T = Kh.Qh + Kh.Ql + Kl.Qh          O^T = Vh.Ph + Vh.Pl + Vl.Ph,
+// instead of eight exact-fp32 MFMAs of twice the cycles (attention_kernel<float>: 16 384 MFMA cycles per wave and 64-key
+// tile, here 1 536).  The probabilities are split in registers after a multiplication by 2^12 (p <= 1: the high half
+// stays in range, the low half stays a normal fp16 number down to p ~ 1e-5; fp32 accumulation makes the scale exact and
+// the final 1 / l takes it back out).  Statistics, softmax and accumulation in fp32 as in the other kernels; the context
+// is written in split-fp16 storage for the output projection.  Same orientation and k-slot maps as attention_kernel:
+// one wave = 16 queries, S^T tiles of 16 keys, V^T read with ds_read_b64_tr_b16 (hi and lo halves apart).
+// LDS images: rows of DK * 4 bytes; physical 16-byte slot = logical slot ^ (row & 15) for K (16-row fragment reads of one
+// slot), ^ 2 (row & 7) for V (8 rows x 32 bytes per LDS cycle of the transposed reads): both conflict-free; the DMA
+// applies the same XOR to its per-lane source slot.  BK keys per tile (64: 128 KB of LDS at dk 128, one workgroup per
+// CU; 32: 64 KB, two).
+typedef _Float16 at_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 at_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mma16h(const at_f16x8& a, const at_f16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <int OFF> __device__ __forceinline__ at_f16x4 lds_read_tr_h(unsigned addr) {
+    at_f16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ void lds_tr_wait_h(at_f16x4 (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+
+constexpr float AT_PSCALE = 4096.0f;
+
+template <int DK, int BK>
+__global__ __launch_bounds__(AT_THREADS, 2) void attention_split_kernel(AttnArgs a) {
+    static_assert(DK == 64 || DK == 128, "split-fp16 attention: head dims whose rows are a power-of-two number of slots");
+    static_assert(BK == 32 || BK == 64, "keys per tile");
+    constexpr int ROWB = DK * 4;                     // bytes per K/V row (split-fp16 storage: 4 bytes per element)
+    constexpr int TILE_BYTES = BK * ROWB;
+    constexpr int PIECES = TILE_BYTES / 1024;        // 1-KiB DMA pieces per tile
+    constexpr int PP = PIECES / 4;                   // per wave
+    constexpr int RPP = 4096 / ROWB;                 // rows between a wave's consecutive pieces
+    constexpr int KS = DK / 32;                      // 32-channel runs = fragment steps over dk
+    constexpr int DT = DK / 16;                      // 16-wide dv tiles
+    constexpr int NT = BK / 16;                      // 16-key score tiles per key tile
+    constexpr int NC = BK / 32;                      // 32-key chunks of the P.V product
+    constexpr int BQ = 64;                           // queries per workgroup
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // stage s: K image at smem + s * 2 * TILE_BYTES, V image right behind it
+
+    int b, h, qblk;
+    if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
+    const int r0 = a.cu[b];
+    const int len = a.cu[b + 1] - r0;
+    if (qblk * BQ >= len) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const unsigned ldb = (unsigned)a.ld * 4u;
+    const unsigned char* __restrict__ base = (const unsigned char*)a.qkv + (size_t)r0 * ldb;
+    const unsigned qcolb = (unsigned)(h * DK) * 4u, kcolb = (unsigned)(a.d + h * DK) * 4u, vcolb = (unsigned)(2 * a.d + h * DK) * 4u;
+
+    // DMA: piece p = wave + 4 pp of an image covers bytes p * 1024 .. of it; this lane's 16 bytes are physical slot
+    // `lslot` of row lrow + RPP * pp
+    const int loff = wave * 1024 + lane * 16;
+    const int lrow = loff / ROWB, lslot = (loff % ROWB) >> 4;
+    auto stage = [&](int kt, int st) __attribute__((always_inline)) {
+        unsigned char* kdst = smem + st * 2 * TILE_BYTES;
+        unsigned char* vdst = kdst + TILE_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const int row = lrow + RPP * pp;
+            int key = k0 + row;
+            key = key < len ? key : len - 1;       // tail keys are masked (-inf); keep the address valid
+            const unsigned char* src = base + (size_t)key * ldb;
+            const unsigned ks_ = (unsigned)(lslot ^ (row & 15)) << 4, vs_ = (unsigned)(lslot ^ (2 * (row & 7))) << 4;
+            __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + kcolb + ks_), (at_lds_void*)(kdst + (wave + 4 * pp) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((at_gbl_void*)(src + vcolb + vs_), (at_lds_void*)(vdst + (wave + 4 * pp) * 1024), 16, 0, 0);
+        }
+    };
+
+    // Q fragments (B operand): Q[q = i][dk = 32 ks + 8 g ..], hi and lo halves
+    const int qrow = qblk * BQ + wave * 16 + i;
+    at_f16x8 qh[KS], ql[KS];
+    {
+        const int qc = qrow < len ? qrow : len - 1;
+        const unsigned char* qb = base + (size_t)qc * ldb + qcolb + g * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qh[ks] = *(const at_f16x8*)(qb + ks * 128);
+            ql[ks] = *(const at_f16x8*)(qb + ks * 128 + 64);
+        }
+    }
+
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_part = 0.f;
+
+    // K fragment (A operand: key i of a 16-key tile, dk 32 ks + 8 g ..): logical slot 8 ks + 4 half + g, physical
+    // slot = logical ^ i: byte kx ^ (128 ks + 64 half) of the tile's first row
+    const int kx = i * ROWB + ((g ^ i) << 4);
+    // V^T fragments: lane 4 q + p of a 16-lane group supplies key row 4 g + q, dv 4 p .. 4 p + 3 of a 16-wide dv tile and
+    // receives the four keys of dv (lane % 16): logical slot 8 (dt / 2) + 4 half + 2 (dt % 2) + p / 2, physical slot =
+    // logical ^ 2 (row & 7)
+    const int vrow = 4 * g + (i >> 2);
+    const int vx = vrow * ROWB + ((((i & 3) >> 1) ^ (2 * (vrow & 7))) << 4) + (i & 1) * 8;
+
+    const int ntiles = (len + BK - 1) / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        vm_wait_barrier<0>();   // tile kt landed (explicit vmcnt(0)) + barrier: every wave is done with the other stage
+        if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
+        const unsigned char* Ks = smem + (kt & 1) * 2 * TILE_BYTES;
+        const unsigned vs = (unsigned)(size_t)(at_lds_void*)(Ks + TILE_BYTES);
+        const int k0 = kt * BK;
+
+        // ---- S^T tiles: s[nt][r] = score(key = k0 + 16 nt + 4 g + r, query i) -------------------------------
+        f32x4 s[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) s[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            at_f16x8 kh[NT], kl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                kh[nt] = *(const at_f16x8*)(Ks + nt * 16 * ROWB + (kx ^ (ks * 128)));
+                kl[nt] = *(const at_f16x8*)(Ks + nt * 16 * ROWB + (kx ^ (ks * 128 + 64)));
+            }
+            // small terms first, one term over all tiles at a time (independent accumulators back to back)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s[nt] = mma16h(kl[nt], qh[ks], s[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s[nt] = mma16h(kh[nt], ql[ks], s[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) s[nt] = mma16h(kh[nt], qh[ks], s[nt]);
+        }
+
+        // ---- online softmax, per query (lane-local; the 4 lane groups hold different keys) -------------------
+        if ((k0 + BK) > len) {     // last tile only: keys beyond the utterance get -inf (exp2 -> exactly 0)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((k0 + nt * 16 + 4 * g + r) >= len) s[nt][r] = -INFINITY;
+        }
+        float m_loc = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = s[nt][r] * a.scale_log2e;     // scale > 0: -inf stays -inf
+                s[nt][r] = v;
+                m_loc = fmaxf(m_loc, v);
+            }
+        m_loc = rows_max(m_loc);
+        const float m_new = fmaxf(m_run, m_loc);     // finite: every tile has >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // v_exp_f32: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[nt][r] - m_new);
+                s[nt][r] = p;
+                psum += p;
+            }
+        l_part = l_part * alpha + psum;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        }
+
+        // ---- O^T += V^T . P^T over the 32-key chunks; k-slot (g, jj) <-> key 32 c + 16 (jj / 4) + 4 g + jj % 4 ---
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            at_f16x8 ph, pl;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float p = s[2 * c + (jj >> 2)][jj & 3] * AT_PSCALE;
+                const _Float16 hh = (_Float16)p;
+                ph[jj] = hh;
+                pl[jj] = (_Float16)(p - (float)hh);
+            }
+#pragma unroll
+            for (int dt0 = 0; dt0 < DT; dt0 += 2) {      // two dv tiles at a time
+                at_f16x4 vf[8];                          // [4 u + 2 half + w]: dv tile dt0 + u, hi / lo, keys 4 g.. / 16 + 4 g..
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int dt = dt0 + u;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const unsigned va = vs + (unsigned)(vx ^ ((((dt >> 1) * 8 + half * 4 + (dt & 1) * 2)) << 4));
+                        vf[4 * u + 2 * half + 0] = lds_read_tr_h<(32 * 0 + 0) * ROWB>(va + c * 32 * ROWB);
+                        vf[4 * u + 2 * half + 1] = lds_read_tr_h<16 * ROWB>(va + c * 32 * ROWB);
+                    }
+                }
+                lds_tr_wait_h(vf);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    at_f16x8 vh, vl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        vh[r] = vf[4 * u + 0][r];
+                        vh[4 + r] = vf[4 * u + 1][r];
+                        vl[r] = vf[4 * u + 2][r];
+                        vl[4 + r] = vf[4 * u + 3][r];
+                    }
+                    o[dt0 + u] = mma16h(vl, ph, o[dt0 + u]);
+                    o[dt0 + u] = mma16h(vh, pl, o[dt0 + u]);
+                    o[dt0 + u] = mma16h(vh, ph, o[dt0 + u]);
+                }
+            }
+        }
+    }
+
+    float l = rows_sum(l_part);
+    const float inv = 1.0f / (l * AT_PSCALE);
+    if (qrow < len) {
+        f16pair_t* dst = (f16pair_t*)a.ctx + (size_t)(r0 + qrow) * a.ldo + h * DK;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 v = o[dt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] *= inv;
+                asm volatile("" : "+v"(v[r]));      // the rounded product is what gets split (as fs2_cast would)
+            }
+            store4<f16pair_t>(dst + dt * 16 + 4 * g, v);
+        }
+    }
+}
+
 // Debug path for calculate_all_attentions (network/fastspeech2.py:305-341): materialises the
 // softmax matrix of one utterance, atten[h][T][T] fp32.  One wave per (head, query) row.
 template <typename T>
@@ -705,6 +943,28 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
     return FS2_OK;
 }
 
+// q | k | v and ctx in split-fp16 storage (dtype code 3)
+template <int DK>
+static int launch_attention_split(const AttnArgs& a, int B, int H, int max_len, hipStream_t stream) {
+    // 32-key tiles: 64 KB of LDS at dk = 128 (two workgroups per CU, and room for another stream's workgroups beside one)
+    static const int bk = FS2_ENV_INT("FS2_ATTN_SPLIT_BK", 32);
+    static const int xcd_on = FS2_ENV_INT("FS2_ATTN_XCD", 1);
+    AttnArgs aa = a;
+    const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 63) / 64, H, B, xcd_on != 0);
+    static unsigned long long ok64 = 0, ok32 = 0;
+    if (bk == 64) {
+        constexpr int lds = 2 * 2 * 64 * DK * 4;
+        fs2_allow_lds((const void*)attention_split_kernel<DK, 64>, lds, &ok64);
+        hipLaunchKernelGGL((attention_split_kernel<DK, 64>), grid, dim3(AT_THREADS), lds, stream, aa);
+    } else {
+        constexpr int lds = 2 * 2 * 32 * DK * 4;
+        fs2_allow_lds((const void*)attention_split_kernel<DK, 32>, lds, &ok32);
+        hipLaunchKernelGGL((attention_split_kernel<DK, 32>), grid, dim3(AT_THREADS), lds, stream, aa);
+    }
+    FS2_CHECK_LAUNCH("fs2_attention");
+    return FS2_OK;
+}
+
 }  // namespace fs2
 
 using namespace fs2;
@@ -712,8 +972,11 @@ using namespace fs2;
 static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
                            int dk, int ld, int ldo, int dtype, Dropout drop, hipStream_t stream) {
     FS2_CHECK_ARG(qkv && ctx && cu && B > 0 && n_heads > 0, "fs2_attention: bad args");
-    FS2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2, "fs2_attention: dtype=%d", dtype);
-    FS2_CHECK_ARG(dtype != 2 || (!lse && !drop.thresh && ldo % 32 == 0 && ((uintptr_t)ctx & 127) == 0),
+    FS2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2 || dtype == 3, "fs2_attention: dtype=%d", dtype);
+    FS2_CHECK_ARG(dtype != 3 || ((dk == 64 || dk == 128) && ld % 32 == 0 && ((uintptr_t)qkv & 127) == 0),
+                  "fs2_attention(split-fp16 q|k|v): head dim %d must be 64 or 128, ld=%d a multiple of 32, qkv 128-byte aligned",
+                  dk, ld);
+    FS2_CHECK_ARG(dtype < 2 || (!lse && !drop.thresh && ldo % 32 == 0 && ((uintptr_t)ctx & 127) == 0),
                   "fs2_attention(f16x3): the split-fp16 context needs ldo=%d in multiples of 32 and 128-byte alignment; "
                   "inference only", ldo);
     FS2_CHECK_ARG(dk == 32 || dk == 64 || dk == 96 || dk == 128, "fs2_attention: head dim %d unsupported (32/64/96/128)",
@@ -727,6 +990,10 @@ static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu
     a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M; a.drop = drop;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dk);
 #define FS2_ATT(TT, DKK) return launch_attention<TT, DKK>(a, B, n_heads, max_len, stream)
+    if (dtype == 3) {          // q | k | v and context in split-fp16 storage, fp16 matrix pipe
+        if (dk == 64) return launch_attention_split<64>(a, B, n_heads, max_len, stream);
+        return launch_attention_split<128>(a, B, n_heads, max_len, stream);
+    }
     if (dtype == 2) {          // fp32 q | k | v, context in split-fp16 storage
         if (dk == 32) return launch_attention<float, 32, f16pair_t>(a, B, n_heads, max_len, stream);
         if (dk == 64) return launch_attention<float, 64, f16pair_t>(a, B, n_heads, max_len, stream);

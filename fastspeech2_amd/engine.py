@@ -240,6 +240,7 @@ class Engine:
                                      cout=w.shape[0], cin=w.shape[1]))
         self.reg_w = False             # True: fs2_gemm_regw for the q | k | v projection of big batches (21.3 vs 22.8 us alone,
                                        # no difference in the overlapped step: bench.py --engine-set reg_w=1)
+        self.split_attention = True    # f16x3 phone-level half: attention on split-fp16 q | k | v (False: fp32 q | k | v, exact-fp32 MFMA)
         self.big_tiles = True          # fs2_conv_gemm256 where fs2_conv_gemm256_plan picks it (False: fs2_conv_gemm always)
         self._pe = None
         self.profile = None     # optional list collecting (tag, kind, work, start_event, end_event): bench.py rooflines
@@ -348,17 +349,21 @@ class Engine:
                 pend = None
             else:
                 a_t = xt
-            split = code == hip.F16X3       # f16x3 half: fp32 q/k/v, fp32 attention, context re-split for the GEMM
+            split = code == hip.F16X3       # f16x3 half: attention statistics in fp32, context in split-fp16 storage
             ac = F32 if split else code
-            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv", out_f32=split)
+            # f16x3: q | k | v leave the projection in split-fp16 storage and the attention products run on the fp16 matrix
+            # pipe too (csrc/attention.hip attention_split_kernel); fp32 q | k | v + exact-fp32 MFMA for head dims that
+            # kernel does not serve and for the attention dumps (fs2_attention_dump reads fp32)
+            split_qkv = split and self.split_attention and self.dk in (64, 128) and attn_dump is None
+            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv", out_f32=split and not split_qkv)
             if attn_dump is not None:
                 attn_dump.append(self._dump_attention(qkv, lens, ac))
-            ctx = self._empty((M, d), code)       # f16x3: written in split-fp16 storage by the fp32 attention kernel
+            ctx = self._empty((M, d), code)       # f16x3: written in split-fp16 storage by the attention kernel
             prof = self.profile is not None and lens is not None
             with self._timed("attention:" + ("fp32" if ac == F32 else "bf16") if prof else None, "flop",
                              4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
-                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d, code,
-                     stream())
+                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d,
+                     hip.F16X3_QKV if split_qkv else code, stream())
             if st.concat_after:
                 att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
                 pend = self._empty((2, M, d), dtype=torch.float32)

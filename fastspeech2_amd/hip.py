@@ -12,6 +12,7 @@ import torch
 from . import build as _build
 
 F32, BF16, F16X3 = 0, 1, 2
+F16X3_QKV = 3        # fs2_attention only: q | k | v AND ctx in split-fp16 storage (products on the fp16 matrix pipe)
 DTYPE_CODE = {"fp32": F32, "bf16": BF16, "f16x3": F16X3}
 # container type of a "T copy": split-fp16 storage is 4 bytes per element (include/fs2_hip.h), held in float32 tensors
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16, F16X3: torch.float32}

@@ -27,6 +27,7 @@ extern "C" {
 
 #define FS2_F32 0
 #define FS2_BF16 1
+#define FS2_F16X3_QKV 3 /* fs2_attention only: q | k | v and ctx in split-fp16 storage */
 #define FS2_F16X3 2   /* split-fp16 storage (see fs2_conv_gemm_f16x3): T copies of fs2_add_layernorm / fs2_cast, f16x3 GEMMs */
 
 #define FS2_OK 0
@@ -144,6 +145,9 @@ int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype);
  * q | k | v with each part [n_heads][dk]; ctx [M, ldo] T.  dk in {32, 64, 96, 128}.
  * dtype 2 (FS2_F16X3): fp32 q | k | v and fp32 arithmetic, ctx written in split-fp16 storage (the operand form of
  * fs2_conv_gemm_f16x3, as fs2_cast would convert it; ldo % 32 == 0, ctx 128-byte aligned).
+ * dtype 3 (FS2_F16X3_QKV): q | k | v in split-fp16 storage as well (what fs2_conv_gemm_f16x3 writes with out_f32 = 0;
+ * ld % 32 == 0, qkv 128-byte aligned, dk in {64, 128}); both products as three fp16 MFMAs (hi.hi + hi.lo + lo.hi, fp32
+ * accumulation and softmax), ctx in split-fp16 storage: fp32-grade results at a fifth of the exact-fp32 MFMA time.
  * Replaces MultiHeadedAttention.forward between the projections (network/encoder.py:73-88). */
 int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
                   int ldo, int dtype, hipStream_t stream);

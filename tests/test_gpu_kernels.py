@@ -413,6 +413,51 @@ def test_attention_split_fp16_context_equals_cast(h, dk, lens):
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
+def _split_values(t):
+    """fp64 values of a tensor in split-fp16 storage (float32 container [M, C]: per run of 32 elements 32 hi halves, then
+    32 lo halves; value = hi + lo)."""
+    M, C = t.shape
+    halves = t.detach().cpu().contiguous().view(torch.float16).view(M, C // 32, 2, 32).double()
+    return (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(M, C)
+
+
+@pytest.mark.parametrize("h,dk,lens", [(2, 128, [120, 64, 33, 1, 200]), (2, 64, [130, 64, 257, 1, 90, 31, 7, 300, 12, 45]),
+                                       (2, 128, [512, 77]), (4, 64, [16, 17, 63, 65])])
+def test_attention_on_split_fp16_operands_is_fp32_grade(h, dk, lens):
+    """fs2_attention dtype 3 (FS2_F16X3_QKV): q | k | v in split-fp16 storage, both products as three fp16 MFMAs
+    (csrc/attention.hip attention_split_kernel), against the fp64 attention of the operand values hi + lo
+    (network/encoder.py:77-88) - and no worse than the exact-fp32 MFMA kernel on the same values."""
+    g = torch.Generator().manual_seed(h * 10 + dk)
+    d, M = h * dk, sum(lens)
+    qkv = torch.randn(M, 3 * d, generator=g)
+    qkv[:, :d] *= 2.0                      # peaky softmax rows
+    qkv[::7, 2 * d:] *= 1e-3               # small v values (low halves near the fp16 subnormal range)
+    q32 = qkv.to(DEV)
+    qs = torch.empty_like(q32)
+    call("fs2_cast", ptr(q32), ptr(qs), M * 3 * d, hip.F16X3, stream())
+    vals = _split_values(qs)
+    outs, r0 = [], 0
+    for L in lens:
+        q = vals[r0:r0 + L, :d].view(L, h, dk).transpose(0, 1)
+        k = vals[r0:r0 + L, d:2 * d].view(L, h, dk).transpose(0, 1)
+        v = vals[r0:r0 + L, 2 * d:].view(L, h, dk).transpose(0, 1)
+        a = torch.softmax(q @ (k.transpose(-2, -1) / math.sqrt(dk)), -1)
+        outs.append((a @ v).transpose(0, 1).reshape(L, d))
+        r0 += L
+    ref = torch.cat(outs, 0)
+    cu_d = torch.from_numpy(_cu(lens)).to(DEV)
+    ctx = torch.full((M, d), float("nan"), device=DEV)
+    call("fs2_attention", ptr(qs), ptr(ctx), ptr(cu_d), len(lens), max(lens), h, dk, 3 * d, d, hip.F16X3_QKV, stream())
+    err = (_split_values(ctx) - ref).abs().max().item()
+    # the exact-fp32 MFMA kernel on the same operand values (hi + lo is exactly representable in fp32)
+    v32 = vals.float().to(DEV)
+    ctx32 = torch.empty((M, d), device=DEV)
+    call("fs2_attention", ptr(v32), ptr(ctx32), ptr(cu_d), len(lens), max(lens), h, dk, 3 * d, d, hip.F32, stream())
+    err32 = (ctx32.cpu().double() - ref).abs().max().item()
+    print("split-fp16 attention h %d dk %d lens %s: max-abs err %.3g (exact-fp32 kernel %.3g)" % (h, dk, lens[:4], err, err32))
+    assert err <= 4e-6, err               # |ctx| ~ 1; the split-fp16 context itself carries 22 bits (2.4e-7)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("h,dk,lens", [(2, 32, [1, 70, 5]), (2, 64, [129, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 64]),
                                        (2, 128, [120, 64, 33, 256]),      # <= 256 keys: the 64-query / 32-key-tile form at dk 128
