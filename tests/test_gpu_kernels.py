@@ -141,6 +141,58 @@ def test_conv_gemm_frame_level_shapes(cin, n, ksplit, lens):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("taps,cin,n,ksplit,lens", [
+    (9, 256, 1024, 1, [700, 3, 1, 64, 192, 191, 193, 2900, 8, 4300, 5200, 1, 2500]),   # 16 268 rows: one 255-row tile per workgroup
+    (9, 1024, 256, 2, [1, 190, 2, 8300, 59, 4100, 7000, 900, 8200]),                    # two K ranges, 225-row tiles
+    (3, 256, 256, 1, [4097, 12, 300]),                                                  # 3 taps, one channel tile, short tiles
+    (9, 256, 512, 1, [256 * 32 + 5]),                                                   # two tiles per workgroup, 16-row second tile
+])
+def test_conv_gemm256_matches_fp32_conv(taps, cin, n, ksplit, lens):
+    """fs2_conv_gemm256 (256 x 256 persistent ping-pong kernel from pre-tiled weights, csrc/conv_gemm256.hip; the engine takes
+    it where fs2_conv_gemm256_plan picks it) against torch's fp32 conv of the same bf16-rounded operands, utterance by
+    utterance (network/encoder.py:16-30), with ReLU / residual / split-K epilogues and ragged utterance edges inside tiles."""
+    code, tdt = hip.DTYPE_CODE["bf16"], torch.bfloat16
+    g = torch.Generator().manual_seed(cin + n + ksplit + taps)
+    M = sum(lens)
+    x = torch.randn(M, cin, generator=g)
+    w = torch.randn(n, cin, taps, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(n, generator=g) * 0.1
+    res = torch.randn(M, n, generator=g)
+    xd, bd, rd = x.to(DEV, tdt).contiguous(), b.to(DEV), res.to(DEV)
+    wd = w.permute(2, 0, 1).to(DEV, tdt).contiguous()
+    wt = torch.empty_like(wd)
+    call("fs2_pack_weight_tiled", ptr(wd), ptr(wt), n, cin, taps, code, stream())
+    wq = w.to(DEV, tdt).float()
+    outs, r0 = [], 0
+    for L in lens:
+        xi = xd[r0:r0 + L].float().t().unsqueeze(0)
+        outs.append(F.conv1d(xi, wq, bd, padding=(taps - 1) // 2).squeeze(0).t())
+        r0 += L
+    ref = torch.cat(outs, 0)
+    _, _, seg, _ = _seg_tables(lens)
+    scale = max(1.0, ref.abs().max().item())
+    if ksplit == 1:
+        for relu, use_res, out_f32 in [(False, False, True), (True, False, False), (False, True, True)]:
+            out = torch.full((M, n), float("nan"), device=DEV, dtype=torch.float32 if out_f32 else tdt)
+            call("fs2_conv_gemm256", ptr(xd), ptr(wt), ptr(bd), ptr(rd) if use_res else None, ptr(out), ptr(seg), M, n, cin,
+                 taps, cin, n, n, int(relu), int(out_f32), code, 1, 0, stream())
+            exp = ref.clamp_min(0) if relu else ref
+            exp = exp + rd if use_res else exp
+            err = (out.float() - exp).abs().max().item()
+            assert err <= (2e-3 if out_f32 else 1e-2) * scale, (relu, use_res, out_f32, err)
+    else:
+        parts = torch.full((ksplit, M, n), float("nan"), device=DEV)
+        call("fs2_conv_gemm256", ptr(xd), ptr(wt), ptr(bd), ptr(rd), ptr(parts), ptr(seg), M, n, cin, taps, cin, n, n, 0, 1,
+             code, ksplit, M * n, stream())
+        err = (parts.sum(0) - (ref + rd)).abs().max().item()
+        assert err <= 2e-3 * scale, err
+    # refusals: shapes the kernel does not serve are errors, not silent fallbacks
+    with pytest.raises(hip.HipError):
+        call("fs2_conv_gemm256", ptr(xd), ptr(wt), ptr(bd), None, ptr(rd), ptr(seg), M, n, cin, 5, cin, n, n, 0, 1, code, 1, 0,
+             stream())
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("taps,cin,n,lens,ksplit", [
     (9, 256, 1024, [120, 61, 1, 3, 700], 1),        # phone-level first FFN conv (64 x 64 tiles)
     (9, 1024, 256, [130, 9, 4000], 3),              # second FFN conv, three K ranges, 128 x 128 tiles

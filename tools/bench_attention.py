@@ -11,7 +11,9 @@ DEV = "cuda:0"
 h, dk = 2, 128
 d = h * dk
 rng = np.random.Generator(np.random.PCG64(0))
-cases = [("config 2 decoder", np.clip(np.rint(rng.normal(800, 100, 32)), 400, 1200).astype(int).tolist()),
+_fix = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "durations_bench32.npz")
+cases = [("bench.py batch", np.load(_fix)["frames"].astype(int).tolist()),     # the frame counts of bench.py's own batch
+         ("config 2 decoder", np.clip(np.rint(rng.normal(800, 100, 32)), 400, 1200).astype(int).tolist()),
          ("config 2 encoder", np.clip(np.rint(rng.normal(120, 15, 32)), 60, 180).astype(int).tolist()),
          ("config 4 B=1", [4165]), ("config 4 B=4", [4165, 4100, 3900, 4000]),
          ("uniform 64 x 1024", [1024] * 64)]      # no imbalance: the tile code's own rate
