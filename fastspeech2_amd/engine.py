@@ -240,6 +240,7 @@ class Engine:
                                      cout=w.shape[0], cin=w.shape[1]))
         self.reg_w = False             # True: fs2_gemm_regw for the q | k | v projection of big batches (21.3 vs 22.8 us alone,
                                        # no difference in the overlapped step: bench.py --engine-set reg_w=1)
+        self.fused_proj_ln = True      # post-LN blocks at d = 256, bf16: output projection + residual + norm1 as one kernel (csrc/proj_ln.hip)
         self.split_attention = True    # f16x3 phone-level half: attention on split-fp16 q | k | v (False: fp32 q | k | v, exact-fp32 MFMA)
         self.big_tiles = True          # fs2_conv_gemm256 where fs2_conv_gemm256_plan picks it (False: fs2_conv_gemm always)
         self._pe = None
@@ -369,6 +370,14 @@ class Engine:
                 pend = self._empty((2, M, d), dtype=torch.float32)
                 self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, out_f32=True, out=pend[0], res=x32)
                 self._gemm(att, L["wc_a"], None, M, d, d, 1, code, out_f32=True, out=pend[1])
+            elif (not st.pre_ln and self.fused_proj_ln and
+                  hip.load().fs2_proj_add_layernorm_plan(int(M), int(d), int(d), int(code))):
+                # post-LN block, d = 256, bf16: norm1(x + linear_out(ctx)) as ONE stream over the rows (csrc/proj_ln.hip)
+                n32, nt_ = self._empty((M, d), dtype=torch.float32), self._empty((M, d), code)
+                with self._timed("proj_ln", "byte", M * d * (2.0 + 4.0 + 4.0 + 2.0) + d * d * 2.0):
+                    call("fs2_proj_add_layernorm", ptr(ctx), ptr(L["wo"]), ptr(L["bo"]), ptr(x32), ptr(L["norm1_w"]),
+                         ptr(L["norm1_b"]), ptr(n32), ptr(nt_), M, d, d, d, d, d, LN_EPS, code, stream())
+                x32, xt, pend = n32, nt_, None
             else:
                 pend = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, out_f32=True, res=x32,
                                   ksplit=self._ksplit(M, d, d, 1, code), tag="out_proj")
@@ -376,7 +385,8 @@ class Engine:
             if st.pre_ln:
                 f_t = self._ln(None, L["norm2_w"], L["norm2_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
             else:
-                x32, xt = self._ln(None, L["norm1_w"], L["norm1_b"], M, d, code, True, True, parts=pend)
+                if pend is not None:
+                    x32, xt = self._ln(None, L["norm1_w"], L["norm1_b"], M, d, code, True, True, parts=pend)
                 f_t = xt
             taps, U = L["taps"], L["units"]
             sg = seg if taps > 1 else None

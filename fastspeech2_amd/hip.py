@@ -39,6 +39,7 @@ _SIGNATURES = {
     "fs2_conv_gemm256": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _P],
     "fs2_pack_weight_tiled": [_P, _P, _I, _I, _I, _I, _P],
     "fs2_gemm_regw": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "fs2_proj_add_layernorm": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "fs2_add_layernorm": [_P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fs2_attention_dump": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -90,6 +91,7 @@ _INT_QUERIES = {
     "fs2_conv_gemm_ksplit": [_I, _I, _I, _I, _I],
     "fs2_conv_gemm256_plan": [_I, _I, _I, _I, _I, _I],
     "fs2_gemm_regw_plan": [_I, _I, _I, _I, _I, _I, _I],
+    "fs2_proj_add_layernorm_plan": [_I, _I, _I, _I],
 }
 EXPORTS = sorted(list(_SIGNATURES) + list(_SIZE_QUERIES) + list(_INT_QUERIES) +
                  ["fs2_last_error", "fs2_abi_version", "fs2_device_arch"])

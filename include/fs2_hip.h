@@ -136,6 +136,17 @@ int fs2_gemm_regw(const void* X, const void* W, const float* bias, void* out, in
                   int out_f32, int dtype, hipStream_t stream);
 int fs2_gemm_regw_plan(int M, int N, int Cin, int dtype, int has_res, int relu, int out_f32);
 
+/* out = LayerNorm(res + X . W^T + bias) (eps as given; gamma / beta [N]) for N = Cin = 256, bf16 operands: the attention
+ * output projection, the residual add and norm1 of a post-LN EncoderLayer (network/encoder.py:89, :171-180 with
+ * normalize_before = False; LayerNorm: network/utils.py:39-47) as ONE stream over the token rows with W in registers
+ * (csrc/proj_ln.hip).  X [M, ldx] bf16, W [N][Cin] bf16, res [M, ldr] fp32, out_f32 [M, ldo] fp32 and out_t [M, ldo]
+ * bf16 (both written).  fs2_proj_add_layernorm_plan: 1 where this kernel serves the shape and is the path to take
+ * (else fs2_conv_gemm with `res` + fs2_add_layernorm); no launch. */
+int fs2_proj_add_layernorm(const void* X, const void* W, const float* bias, const float* res, const float* gamma,
+                           const float* beta, float* out_f32, void* out_t, int M, int N, int Cin, int ldx, int ldr, int ldo,
+                           float eps, int dtype, hipStream_t stream);
+int fs2_proj_add_layernorm_plan(int M, int N, int Cin, int dtype);
+
 /* Split-K factor (>= 1) the launch schedules pass as `ksplit` for a GEMM of this shape whose partial outputs
  * an fs2_add_layernorm call sums: 1 unless the tiling would leave most CUs idle.  No launch; no counterpart in
  * the reference (it is part of the kernel dispatch). */

@@ -465,6 +465,41 @@ def test_attention_split_fp16_context_equals_cast(h, dk, lens):
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
+@pytest.mark.parametrize("M", [16, 2049, 25611, 4097 * 3 + 5])
+def test_proj_add_layernorm_matches_fp64(M):
+    """fs2_proj_add_layernorm (csrc/proj_ln.hip): LayerNorm(res + X . W^T + bias), eps 1e-12 (network/encoder.py:89, :171-180;
+    network/utils.py:39-47) against fp64 on the bf16 operands; and against the two-launch path it replaces."""
+    g = torch.Generator().manual_seed(M)
+    d = 256
+    x = torch.randn(M, d, generator=g).to(torch.bfloat16)
+    w = (torch.randn(d, d, generator=g) / 16).to(torch.bfloat16)
+    b = torch.randn(d, generator=g) * 0.1
+    res = torch.randn(M, d, generator=g) * 2.0 + 0.5
+    gam, bet = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    y = res.double() + x.double() @ w.double().t() + b.double()
+    mu = y.mean(-1, keepdim=True)
+    var = ((y - mu) ** 2).mean(-1, keepdim=True)
+    ref = (y - mu) / torch.sqrt(var + 1e-12) * gam.double() + bet.double()
+    xd, wd, bd, rd, gd, ed = (t.to(DEV).contiguous() for t in (x, w, b, res, gam, bet))
+    o32 = torch.full((M, d), float("nan"), device=DEV)
+    ot = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    call("fs2_proj_add_layernorm", ptr(xd), ptr(wd), ptr(bd), ptr(rd), ptr(gd), ptr(ed), ptr(o32), ptr(ot), M, d, d, d, d, d,
+         1e-12, hip.BF16, stream())
+    err = (o32.cpu().double() - ref).abs().max().item()
+    print("proj_add_layernorm M %d: max-abs err %.3g" % (M, err))
+    assert err <= 2e-5, err
+    assert torch.equal(ot.cpu(), o32.cpu().to(torch.bfloat16))
+    # the two launches it replaces: GEMM with the residual in its epilogue, then add + LayerNorm
+    part = torch.empty((M, d), device=DEV)
+    call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), ptr(rd), ptr(part), None, M, d, d, 1, d, d, d, 0, 1, hip.BF16, 1, 0, stream())
+    p32, pt = torch.empty((M, d), device=DEV), torch.empty((M, d), device=DEV, dtype=torch.bfloat16)
+    call("fs2_add_layernorm", None, ptr(part), 1, M * d, ptr(gd), ptr(ed), None, ptr(p32), ptr(pt), M, d, 1e-12, hip.BF16, stream())
+    assert (o32 - p32).abs().max().item() <= 2e-5
+    with pytest.raises(hip.HipError):
+        call("fs2_proj_add_layernorm", ptr(xd), ptr(wd), ptr(bd), ptr(rd), ptr(gd), ptr(ed), ptr(o32), ptr(ot), M, 384, 384, 384,
+             384, 384, 1e-12, hip.BF16, stream())
+
+
 def _split_values(t):
     """fp64 values of a tensor in split-fp16 storage (float32 container [M, C]: per run of 32 elements 32 hi halves, then
     32 lo halves; value = hi + lo)."""

@@ -49,3 +49,29 @@ if not only or only == "qkv_regw":
     us = e0.elapsed_time(e1) / n * 1e3
     nbytes = M * K * 2 + N * K * 2 + M * N * 2
     print("qkv_regw  M=%d N=%d K=%d: %.1f us  %.0f TFLOP/s  %.0f GB/s of algorithmic bytes" % (M, N, K, us, 2.0 * M * N * K / us * 1e-6, nbytes / us * 1e-3), flush=True)
+if not only or only == "proj_ln":
+    # output projection + residual + norm1 as one kernel (csrc/proj_ln.hip) against the two launches it replaces
+    N = K = 256
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) / 16).to(torch.bfloat16)
+    b, gam, bet = torch.zeros(N, device=dev), torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    res = torch.randn(M, N, device=dev)
+    part, o32 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ot = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    def fused():
+        call("fs2_proj_add_layernorm", ptr(x), ptr(w), ptr(b), ptr(res), ptr(gam), ptr(bet), ptr(o32), ptr(ot), M, N, K, K, N, N,
+             1e-12, 1, stream())
+    def pair():
+        call("fs2_conv_gemm", ptr(x), ptr(w), ptr(b), ptr(res), ptr(part), None, M, N, K, 1, K, N, N, 0, 1, 1, 1, 0, stream())
+        call("fs2_add_layernorm", None, ptr(part), 1, M * N, ptr(gam), ptr(bet), None, ptr(o32), ptr(ot), M, N, 1e-12, 1, stream())
+    nbytes = M * N * (2 + 4 + 4 + 2) + N * K * 2
+    for name, run in (("pair", pair), ("fused", fused), ("pair", pair), ("fused", fused)):
+        for _ in range(5): run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        n = 12 if only else 50
+        for _ in range(n): run()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        print("out_proj + residual + norm1, %-5s M=%d: %.1f us  %.0f GB/s of the fused kernel's algorithmic bytes (%.1f MB)"
+              % (name, M, us, nbytes / us * 1e-3, nbytes * 1e-6), flush=True)
