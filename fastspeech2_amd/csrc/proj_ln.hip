@@ -104,9 +104,14 @@ __global__ __launch_bounds__(256, PL_WGS) void proj_ln_kernel(ProjLnArgs a) {
                                              (pl_lds_void*)(rs + r * 1024), 16, 0, 0);
         }
     };
-#pragma unroll
-    for (int k = 0; k < PL_RING - 1; ++k) issue_piece(k, k);
 
+    {   // bias | gamma | beta into LDS (read back per piece: the registers hold W); first, so that the wait for these
+        // three loads does not take the loads of W with it
+        float* vec = (float*)(smem + PL_VEC);
+        vec[tid] = a.bias ? a.bias[tid] : 0.f;
+        vec[PL_K + tid] = a.gamma[tid];
+        vec[2 * PL_K + tid] = a.beta[tid];
+    }
     // ---- W in registers: fragment (nt, ks) = row 64 w + 16 nt + i, k = 32 ks + 8 g .. + 7; per-channel vectors of the
     //      lane's channels 64 w + 16 nt + 4 g + r
     bf16x8 wf[4][8];
@@ -118,13 +123,16 @@ __global__ __launch_bounds__(256, PL_WGS) void proj_ln_kernel(ProjLnArgs a) {
             for (int ks = 0; ks < 8; ++ks) wf[nt][ks] = *(const bf16x8*)(wp + (size_t)nt * 16 * PL_K + ks * 32);
     }
     const int cbase = wave * 64 + 4 * g;               // channel of (nt, r): cbase + 16 nt + r
-    {   // bias | gamma | beta into LDS (read back per piece: the registers hold W)
-        float* vec = (float*)(smem + PL_VEC);
-        vec[tid] = a.bias ? a.bias[tid] : 0.f;
-        vec[PL_K + tid] = a.gamma[tid];
-        vec[2 * PL_K + tid] = a.beta[tid];
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0) lgkmcnt(0) as the builtin: W has arrived, the vectors are in LDS
+    // the first pieces go out BEHIND the loads of W and the vectors: the in-order vmcnt then lets the loop start on piece 0
+    // while pieces 1 .. are still on their way
+#pragma unroll
+    for (int k = 0; k < PL_RING - 1; ++k) issue_piece(k, k);
+    // W, the vectors and piece 0 have arrived (all but the DMA of the later pieces), the vectors are in LDS
+    // (as the builtin, so that hipcc's own wait insertion knows W has arrived and adds no vmcnt(0) in front of the MFMAs;
+    //  encoding: vmcnt in bits 3:0 (< 16 here), expcnt 6:4 at its maximum, lgkmcnt 11:8 = 0)
+    static_assert((PL_RING - 2) * PL_DMA < 16, "vmcnt field");
+    __builtin_amdgcn_s_waitcnt(0x0070 | ((PL_RING - 2) * PL_DMA));
+    __builtin_amdgcn_sched_barrier(0);
 
     float* ex = (float*)(smem + PL_EX);                // [2][4][16]
     const unsigned xlane = (unsigned)(i * 512);
@@ -133,8 +141,12 @@ __global__ __launch_bounds__(256, PL_WGS) void proj_ln_kernel(ProjLnArgs a) {
         const int slot = p % PL_RING;
         // piece p landed: all but the PL_INFLIGHT youngest vector-memory instructions of this wave are done (issued since
         // its DMA, with a ring of three: stores of p - 2, DMA of p + 1, stores of p - 1), then every wave's
-        if (p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the prologue's counts differ)
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL_INFLIGHT) : "memory");
+        // (the first trips have fewer stores behind them: piece p < PL_RING - 1 was issued in the prologue, in front of
+        // the DMA of pieces p + 1 .. PL_RING - 2, and trips 0 .. p - 1 issued PL_DMA + PL_STORES instructions each)
+        if (p >= PL_RING - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL_INFLIGHT) : "memory");
+        else if (p == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PL_RING - 2) * PL_DMA) : "memory");
+        else if (p == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PL_RING - 3 > 0 ? PL_RING - 3 : 0) * PL_DMA + PL_DMA + PL_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PL_DMA + PL_STORES)) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
