@@ -245,6 +245,55 @@ def test_f16x3_encoder_durations_equal_the_fp32_engine_on_the_bench_batch():
     assert worst <= 5e-6, worst          # fp32 summation-order noise level (measured 1e-6; bf16 encoder: 4e-3)
 
 
+@pytest.mark.parametrize("variant", ["small_ln_outputs", "large_ffn_hidden"])
+def test_f16x3_encoder_on_rescaled_weights(variant):
+    """The f16x3 mode splits activations UNSCALED into fp16 pairs (include/fs2_hip.h): operands far from 1 lose low-half
+    bits (|x| < ~1e-3: the low half goes subnormal) or overflow (|x| > 65504).  Two function-preserving rescalings of the
+    bench model push the phone-level operands towards those edges: LayerNorm outputs 64 x smaller with the weights that
+    read them 64 x larger, and FFN hidden activations 16 x larger with the second conv 16 x smaller.  Durations must still
+    equal the exact-fp32 engine's on the bench batch; the log-duration distance is printed (parity on real checkpoints
+    remains unpinned: there are none here)."""
+    from fastspeech2_amd import synth
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = {k: v.copy() for k, v in synth.bench_state_dict().items()}
+    for li in range(kw["elayers"]):
+        p = "encoder.encoders.%d." % li
+        if variant == "small_ln_outputs":
+            # x = norm(...) feeds the next block's q / k / v projections and FFN conv 1 (and the residual stream, which the
+            # next LayerNorm renormalises): scale norm2's affine down and every reader of the block input up
+            for n in ("norm1", "norm2"):
+                sd[p + n + ".weight"] /= 64.0
+                sd[p + n + ".bias"] /= 64.0
+            sd[p + "feed_forward.w1.weight"] *= 64.0      # reads norm1's output (64 x smaller)
+            sd[p + "feed_forward.w2.weight"] /= 64.0      # its output joins a 64 x smaller residual stream
+            sd[p + "feed_forward.w2.bias"] /= 64.0
+            if li > 0:          # block input 64 x smaller (block 0 reads the embedding, left as it is)
+                for n in "qkv":
+                    sd[p + "self_atten.linear_%s.weight" % n] *= 64.0
+                sd[p + "self_atten.linear_out.weight"] /= 64.0
+                sd[p + "self_atten.linear_out.bias"] /= 64.0
+        else:
+            sd[p + "feed_forward.w1.weight"] *= 16.0
+            sd[p + "feed_forward.w1.bias"] *= 16.0
+            sd[p + "feed_forward.w2.weight"] /= 16.0
+    if variant == "small_ln_outputs":      # the duration predictor reads the 64 x smaller encoder output
+        sd["variance_adaptor.duration_predictor.conv.0.0.conv.weight"] *= 64.0
+    xs = [torch.from_numpy(x) for x in synth.synth_utterances(32, 0)]
+    res = {}
+    for enc in ("fp32", "f16x3"):
+        model = FeedForwardTransformer(80, 80, use_scaled_pos_enc=True, **kw)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        model.eval().cuda().set_precision("bf16", enc)
+        pk = model.infer_batch(xs)["packed"]
+        res[enc] = (pk["durations_pred"].cpu().numpy(), pk["log_durations"].cpu().numpy())
+    differ = int((res["fp32"][0] != res["f16x3"][0]).sum())
+    dist = float(np.abs(res["fp32"][1] - res["f16x3"][1]).max())
+    print("f16x3 on %s: %d of %d durations differ from the fp32 engine, max |logd difference| %.2e"
+          % (variant, differ, res["fp32"][0].size, dist))
+    assert np.isfinite(res["f16x3"][1]).all()
+    assert differ == 0 and dist <= 2e-5
+
+
 @pytest.mark.parametrize("precision", [("fp32", None), ("bf16", "f16x3")])
 @pytest.mark.parametrize("name", sorted(helpers.DURATION_CASES))
 def test_durations_of_the_full_workloads_equal_the_reference(name, precision):
