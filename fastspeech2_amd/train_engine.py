@@ -177,9 +177,13 @@ class TrainEngine:
         self.energy_pred = dict(self._pred_weights(va + "energy_predictor."), rate_key="var", site=(2 << 16) + 48)
         self.w_out = _Weight([self.P["feat_out.weight"]], self.tdt, self.dev, pad_n=self.odim_pad)
         wp, we = self.P[va + "pitch_embed.conv.conv.weight"], self.P[va + "energy_embed.conv.conv.weight"]
-        if wp.shape[-1] != 1 or we.shape[-1] != 1:
-            raise NotImplementedError("pitch/energy embed kernel size must be 1")
         self.pdim, self.edim = wp.shape[1], we.shape[1]
+        # pitch / energy_embed_kernel_size (network/variance_adaptor.py:35-51, any odd k): 1 = the reference default, folded
+        # into the add kernel; larger kernels are convs over time inside each utterance (fp32 fs2_conv_gemm over inputs
+        # padded to 4 channels, fs2_conv_wgrad for the gradients)
+        self.embed_taps = (int(wp.shape[-1]), int(we.shape[-1]))
+        if any(k % 2 == 0 or k > 9 for k in self.embed_taps):
+            raise NotImplementedError("pitch/energy embed kernel sizes must be odd and <= 9")
         # repaired PostNet (network/fastspeech2.py:13-54): conv (no bias) -> BatchNorm -> tanh -> dropout
         self.post = []
         n = cfg["postnet_layers"]
@@ -788,7 +792,32 @@ class TrainEngine:
         hs_in = hs_lr32
         w_pe, b_pe = P[va + "pitch_embed.conv.conv.weight"], P[va + "pitch_embed.conv.conv.bias"]
         w_ee, b_ee = P[va + "energy_embed.conv.conv.weight"], P[va + "energy_embed.conv.conv.bias"]
-        if r_pe > 0.0 or r_ee > 0.0:
+        conv_emb = self.embed_taps != (1, 1)
+        emb_x4 = None
+        if conv_emb:
+            # embedding convs with kernel size > 1: each embedding = fp32 fs2_conv_gemm ("same" zero padding inside each
+            # utterance) over its input padded to 4 channels (16-byte rows); dropped out with their own sites, added to hs_lr
+            emb = self._empty((2, Mf, d), torch.float32)
+            emb_x4 = []
+            for j, (vals, w, b, site, rate) in enumerate(((ps, w_pe, b_pe, self.SITE_PITCH_EMB, r_pe),
+                                                          (es, w_ee, b_ee, self.SITE_ENERGY_EMB, r_ee))):
+                taps, c = int(w.shape[-1]), int(w.shape[1])
+                c4 = (c + 3) // 4 * 4
+                x4 = torch.zeros((Mf, c4), device=self.dev, dtype=torch.float32)
+                x4[:, :c].copy_(vals)
+                wk = torch.zeros((taps, d, c4), device=self.dev, dtype=torch.float32)
+                wk[:, :, :c].copy_(w.detach().permute(2, 0, 1))
+                call("fs2_conv_gemm", ptr(x4), ptr(wk), ptr(b), None, ptr(emb[j]), ptr(seg_f) if taps > 1 else None, Mf, d, c4,
+                     taps, c4, d, d, 0, 1, F32, 1, 0, stream())
+                if rate > 0.0:
+                    call("fs2_dropout", ptr(emb[j]), None, Mf, d, self.seed, site, rate, F32, stream())
+                emb_x4.append(x4)
+            hs_in = self._empty((Mf, d), torch.float32)
+            call("fs2_add_layernorm", ptr(hs_lr32), ptr(emb), 2, Mf * d, None, None, ptr(hs_in), None, None, Mf, d, LN_EPS,
+                 F32, stream())
+            w_pe, b_pe, w_ee, b_ee = (torch.zeros((d, t.shape[1]), device=self.dev) if t.dim() == 3 else torch.zeros_like(t)
+                                      for t in (w_pe, b_pe, w_ee, b_ee))
+        elif r_pe > 0.0 or r_ee > 0.0:
             # nn.Dropout inside VarianceEmbedding (network/variance_adaptor.py:35-51; reference default 0): the two
             # embeddings are formed apart ([Mf, 4] x [4, d] and [Mf, 1] x [1, d]), dropped out and added to hs_lr; the
             # fused kernel then runs with zero embedding weights
@@ -830,7 +859,7 @@ class TrainEngine:
                      post=post_saved,
                      cu_phone=cu_phone, cu_frames=cu_frames, seg_p=seg_p, seg_f=seg_f, pos_p=pos_p, pos_f=pos_f,
                      dur_used=dur_used, cum=cum, enc=enc_saved, dec=dec_saved, dur=dur_saved, pitch=pitch_saved,
-                     energy=energy_saved, hst=hst, hs_lrt=hs_lrt, zt=zt, before=before, logd=logd, pitch_out=pitch,
+                     energy=energy_saved, hst=hst, hs_lrt=hs_lrt, zt=zt, emb_x4=emb_x4, before=before, logd=logd, pitch_out=pitch,
                      energy_out=energy, xscale=xscale, seed=self.seed, drop_on=self.drop_on, keep=(olens_dev, lr_index, hs_lr32, x32, y32, z32))
         outs = dict(before=before, log_durations=logd.view(-1), pitch=pitch, energy=energy)
         if after is not None:
@@ -889,7 +918,24 @@ class TrainEngine:
             torch.sum(tmp, 0, out=G["decoder.embed.0.alpha"])
         r_pe, r_ee = self._rate("pitch_embed"), self._rate("energy_embed")
         ones = torch.ones((Mf, 1), device=self.dev)
-        if r_pe > 0.0 or r_ee > 0.0:       # every embedding has its own mask: gradient = column sums of mask o dy
+        if s["emb_x4"] is not None:        # embedding convs with kernel size > 1: weight + bias gradients by fs2_conv_wgrad (fp32)
+            for key, x4, dim, site, rate in (("pitch_embed", s["emb_x4"][0], self.pdim, self.SITE_PITCH_EMB, r_pe),
+                                             ("energy_embed", s["emb_x4"][1], self.edim, self.SITE_ENERGY_EMB, r_ee)):
+                g = dy
+                if rate > 0.0:
+                    g = dy.clone()
+                    call("fs2_dropout", ptr(g), None, Mf, d, self.seed, site, rate, F32, stream())
+                taps = int(G[va + key + ".conv.conv.weight"].shape[-1])
+                c4 = x4.shape[1]
+                gw = self._empty((d, c4, taps), torch.float32)
+                gb = self._empty((d,), torch.float32)
+                ks = max(1, min(16, Mf // 256))
+                ws = self._ws(hip.load().fs2_conv_wgrad_workspace(d, c4, taps, ks))
+                call("fs2_conv_wgrad", ptr(g), ptr(x4), ptr(gw), ptr(gb), ptr(ws), ptr(s["seg_f"]) if taps > 1 else None, Mf, d,
+                     c4, taps, d, c4, F32, ks, float(s["xscale"]), 0, stream())
+                G[va + key + ".conv.conv.weight"].copy_(gw[:, :dim, :])
+                G[va + key + ".conv.conv.bias"].copy_(gb)
+        elif r_pe > 0.0 or r_ee > 0.0:     # every embedding has its own mask: gradient = column sums of mask o dy
             for key, vals, dim, site, rate in (("pitch_embed", s["ps"], self.pdim, self.SITE_PITCH_EMB, r_pe),
                                                ("energy_embed", s["es"], self.edim, self.SITE_ENERGY_EMB, r_ee)):
                 g = dy

@@ -254,6 +254,9 @@ def main():
         if "embed_kernels_tiny" in only:
             run_inference_case("embed_kernels_tiny", dict(TINY_B, pitch_embed_kernel_size=3, energy_embed_kernel_size=5), 20,
                                math.log(3.0), [2, 17, 33], alpha=0.8)
+        if "train_embed_kernels_tiny" in only:
+            run_train_case("train_embed_kernels_tiny", dict(TINY_B, pitch_embed_kernel_size=3, energy_embed_kernel_size=5), 21,
+                           math.log(3.0), B=3, Tp=12, alpha=0.8)
         if "train_baseline_b32" in only:
             run_train_case("train_baseline_b32", BASELINE, 1234, math.log(7.67), B=32, Tp=120, ds_lo=1, ds_hi=13,
                            store_inputs=False)
@@ -279,6 +282,8 @@ def main():
     run_train_case("train_tiny_conv9", TINY_A, 11, math.log(4.0), B=3, Tp=9)
     run_train_case("train_tiny_linear", TINY_B, 12, math.log(3.0), B=2, Tp=14, alpha=0.8)
     run_train_case("train_tiny_conv3_mixed", TINY_C, 13, math.log(5.0), B=2, Tp=10, alpha=1.1)
+    run_train_case("train_embed_kernels_tiny", dict(TINY_B, pitch_embed_kernel_size=3, energy_embed_kernel_size=5), 21,
+                   math.log(3.0), B=3, Tp=12, alpha=0.8)
     run_long_case("long_512", BASELINE, 1234, math.log(8.8), 512, 0.15)
     run_train_case("train_baseline_b32", BASELINE, 1234, math.log(7.67), B=32, Tp=120, ds_lo=1, ds_hi=13, store_inputs=False)
     durations_cases()
