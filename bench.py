@@ -286,9 +286,13 @@ def main():
                          "kernel symbol; timed one forward at a time, i.e. without the cross-batch overlap of the "
                          "throughput loop)" % (args.dtype, "" if args.encoder_dtype != args.dtype else " and the phone-level half"))
         traffic = None     # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        tpath = os.path.join(ROOT, "profiles", "r02_ffn_conv_traffic.json")
-        if args.dtype == "bf16" and os.path.isfile(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        # (a PMC pass cannot run inside this process: the figure is the newest committed measurement of the same kernel
+        #  on the same launches - tools/collect_round.sh: FETCH_SIZE / WRITE_SIZE passes over tools/ffn_conv_replay.py)
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_ffn_conv_traffic.json")))
+        if args.dtype == "bf16" and tfiles:
+            traffic = json.load(open(tfiles[-1])).get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
         roofline["traffic"] = traffic
         rooflines = {}
         d = args.dtype
