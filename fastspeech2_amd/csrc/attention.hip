@@ -645,14 +645,24 @@ typedef _Float16 at_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mma16h(const at_f16x8& a, const at_f16x8& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-template <int OFF> __device__ __forceinline__ at_f16x4 lds_read_tr_h(unsigned addr) {
-    at_f16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ void lds_tr_wait_h(at_f16x4 (&v)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+// Eight transposed reads (four addresses, each at +0 and +OFF bytes) AND their wait in ONE asm statement: the results are
+// valid when the statement ends, so nothing the compiler does with the registers afterwards (copies, spills) can see
+// them early - attention32_kernel issues and waits in separate statements to overlap more and leans on tools/isa_check.py
+// rule (c) for that.  "=&v": the outputs must not share registers with the addresses still to be used.
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr8_h(at_f16x4 (&v)[8], unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                 "ds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %2, %9\n\t"
+                 "ds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %4, %10\n\t"
+                 "ds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %6, %11\n\t"
+                 "ds_read_b64_tr_b16 %7, %11 offset:%12\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(OFF)
+                 : "memory");
 }
 
 constexpr float AT_PSCALE = 4096.0f;
@@ -817,17 +827,14 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_split_kernel(AttnArgs
 #pragma unroll
             for (int dt0 = 0; dt0 < DT; dt0 += 2) {      // two dv tiles at a time
                 at_f16x4 vf[8];                          // [4 u + 2 half + w]: dv tile dt0 + u, hi / lo, keys 4 g.. / 16 + 4 g..
+                unsigned va[4];                          // [2 u + half]
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int dt = dt0 + u;
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const unsigned va = vs + (unsigned)(vx ^ ((((dt >> 1) * 8 + half * 4 + (dt & 1) * 2)) << 4));
-                        vf[4 * u + 2 * half + 0] = lds_read_tr_h<(32 * 0 + 0) * ROWB>(va + c * 32 * ROWB);
-                        vf[4 * u + 2 * half + 1] = lds_read_tr_h<16 * ROWB>(va + c * 32 * ROWB);
-                    }
-                }
-                lds_tr_wait_h(vf);
+                    for (int half = 0; half < 2; ++half)
+                        va[2 * u + half] = vs + (unsigned)(c * 32 * ROWB) +
+                                           (unsigned)(vx ^ (((((dt0 + u) >> 1) * 8 + half * 4 + ((dt0 + u) & 1) * 2)) << 4));
+                lds_read_tr8_h<16 * ROWB>(vf, va[0], va[1], va[2], va[3]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     at_f16x8 vh, vl;

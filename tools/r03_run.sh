@@ -1,5 +1,3 @@
 set -e
-for v in "" variants/libfs2_w1p32.so variants/libfs2_w2p32.so variants/libfs2_w2p16.so; do
-echo "== lib: $v"; if [ -n "$v" ]; then export FS2_LIB=$v; fi
-K1_SHAPE=qkv_regw timeout -k 10 100 python tools/k1_probe.py 2>&1 | grep regw
-done
+timeout -k 10 200 python -u -m pytest tests/test_gpu_kernels.py -x -q -k "attention" --timeout 120 --timeout-method thread -s 2>&1 | grep "split-fp16\|passed\|failed"
+timeout -k 10 100 python tools/bench_phone_attention.py 2>&1 | grep -v amdgpu
