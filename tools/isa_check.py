@@ -35,7 +35,7 @@ import tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # kernels whose source waits for asynchronous loads by hand (inline-asm ds_read_b64_tr_b16, counted vmcnt)
-NO_SCRATCH = ("attention32_kernel", "attention_split_kernel", "proj_ln_kernel", "conv_gemm256_kernel", "conv_wgrad_kernelIDF16b", "attn_bwd_dq_kernelIDF16b",
+NO_SCRATCH = ("attention32_kernel", "attention_split_kernel", "proj_ln_kernel", "gemm_regw_kernel", "conv_gemm256_kernel", "conv_wgrad_kernelIDF16b", "attn_bwd_dq_kernelIDF16b",
               "attn_bwd_dkv_kernelIDF16b")
 READLANE_WINDOW = 8
 
