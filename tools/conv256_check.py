@@ -40,7 +40,8 @@ def main():
             call("fs2_pack_weight_tiled", ptr(w), ptr(wt), N, Cin, taps, 1, stream())
             ks_new = lib.fs2_conv_gemm256_plan(M, N, Cin, taps, 1, split)
             ks_old = lib.fs2_conv_gemm_ksplit(M, N, Cin, taps, 1) if split else 1
-            assert ks_new >= 1, "shape not served"
+            if ks_new < 1:      # the plan prefers fs2_conv_gemm for this M: measure the new kernel all the same
+                ks_new = 2 if split else 1
             out_f32 = 1 if split else 0
             dt = torch.float32 if out_f32 else torch.bfloat16
             o_old = torch.zeros((ks_old, M, N), dtype=dt, device=dev)
