@@ -30,6 +30,9 @@ constexpr int PL_ROWS = 16;                         // rows per piece
 constexpr int PL_XB = PL_ROWS * PL_K * 2;           // 8 KB of X per piece
 constexpr int PL_RB = PL_ROWS * PL_K * 4;           // 16 KB of residual per piece
 constexpr int PL_SLOT = PL_XB + PL_RB;              // 24 KB
+// Timing ablations (tools/build_variant.sh TAG -DPL_DBG_NOSTORE | -DPL_DBG_NOLN | -DPL_WGS=2; results are wrong with the
+// first two): without the output stores (16 us instead of 22), without the two LayerNorm exchanges (-1 us), two
+// workgroups per CU on a ring of three (24.1 us).
 #ifndef PL_WGS
 #define PL_WGS 1                                    // workgroups per CU (2: ring of three, 75 KB of LDS each; measured 24.1 vs 22.8 us)
 #endif
