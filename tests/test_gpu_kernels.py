@@ -465,7 +465,7 @@ def test_attention_split_fp16_context_equals_cast(h, dk, lens):
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
 
 
-@pytest.mark.parametrize("M", [16, 2049, 25611, 4097 * 3 + 5])
+@pytest.mark.parametrize("M", [1, 16, 17, 2049, 4096 + 15, 25611, 4097 * 3 + 5, 256 * 16 * 3 + 1])
 def test_proj_add_layernorm_matches_fp64(M):
     """fs2_proj_add_layernorm (csrc/proj_ln.hip): LayerNorm(res + X . W^T + bias), eps 1e-12 (network/encoder.py:89, :171-180;
     network/utils.py:39-47) against fp64 on the bf16 operands; and against the two-launch path it replaces."""
@@ -498,6 +498,45 @@ def test_proj_add_layernorm_matches_fp64(M):
     with pytest.raises(hip.HipError):
         call("fs2_proj_add_layernorm", ptr(xd), ptr(wd), ptr(bd), ptr(rd), ptr(gd), ptr(ed), ptr(o32), ptr(ot), M, 384, 384, 384,
              384, 384, 1e-12, hip.BF16, stream())
+
+
+def test_counted_wait_kernels_are_bit_stable_beside_a_busy_stream():
+    """fs2_proj_add_layernorm and fs2_gemm_regw wait for their LDS-DMA pieces with hand-counted `vmcnt`s (the stores in
+    between are part of the count): a miscount shows as a piece read before it landed, i.e. as run-to-run differences -
+    most likely when another stream's GEMM keeps the memory system busy.  40 launches each beside fs2_conv_gemm on a
+    second stream: every output bit-identical to the first."""
+    g = torch.Generator().manual_seed(5)
+    M, d = 25611, 256
+    x = torch.randn(M, d, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(d, d, generator=g) / 16).to(torch.bfloat16).to(DEV)
+    w3 = (torch.randn(3 * d, d, generator=g) / 16).to(torch.bfloat16).to(DEV)
+    b, gam, bet = (torch.randn(n, generator=g).to(DEV) for n in (3 * d, d, d))
+    res = torch.randn(M, d, generator=g).to(DEV)
+    o32, ot = torch.empty((M, d), device=DEV), torch.empty((M, d), device=DEV, dtype=torch.bfloat16)
+    q = torch.empty((M, 3 * d), device=DEV, dtype=torch.bfloat16)
+    # the busy stream: k = 9 FFN-conv-shaped GEMMs
+    taps, U = 9, 1024
+    wc = (torch.randn(taps, U, d, generator=g) / 48).to(torch.bfloat16).to(DEV)
+    _, _, seg, _ = _seg_tables([M])
+    hbuf = torch.empty((M, U), device=DEV, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(40):
+        with torch.cuda.stream(side):
+            call("fs2_conv_gemm", ptr(x), ptr(wc), None, None, ptr(hbuf), ptr(seg), M, U, d, taps, d, U, U, 1, 0, hip.BF16, 1, 0,
+                 stream())
+        o32.fill_(float("nan")); ot.zero_(); q.zero_()
+        call("fs2_proj_add_layernorm", ptr(x), ptr(w), ptr(b), ptr(res), ptr(gam), ptr(bet), ptr(o32), ptr(ot), M, d, d, d, d, d,
+             1e-12, hip.BF16, stream())
+        call("fs2_gemm_regw", ptr(x), ptr(w3), ptr(b), ptr(q), M, 3 * d, d, d, 3 * d, 0, hip.BF16, stream())
+        torch.cuda.synchronize()
+        cur = (o32.clone(), ot.clone(), q.clone())
+        if first is None:
+            first = cur
+        else:
+            for a, c in zip(first, cur):
+                assert torch.equal(a.view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32),
+                                   c.view(torch.int16 if c.dtype == torch.bfloat16 else torch.int32)), "launch %d differs" % it
 
 
 def _split_values(t):
