@@ -578,14 +578,21 @@ static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
 static int dispatch_conv_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
     static const int forced = FS2_ENV_INT("FS2_SPLIT_TILE", 0);   // experiments: 22, 24, 42, 44
-    if (forced == 22) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
+    if (forced == 22) return launch_conv_gemm<float, 2, 2, 2, 1, true, 4, 0, true>(a, stream);
     if (forced == 24) return launch_conv_gemm<float, 2, 4, 2, 1, false, 3, 0, true>(a, stream);
     if (forced == 42) return launch_conv_gemm<float, 4, 2, 2, 1, false, 3, 0, true>(a, stream);
     if (forced == 44) return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
     // 128 x 128 tiles down to 64 workgroups: alone, 64-row tiles are up to 15 % faster on these launches (more
     // workgroups per CU to hide the stage latency), but the phone-level half runs beside the frame-level kernels of the
     // previous batch, and there the fewer, larger workgroups win (bench step 1.994 vs 2.02 / 2.03 ms, A/B/A/B on one box)
-    if (big_blocks < 64) return launch_conv_gemm<float, 2, 2, 2, 1, false, 4, 0, true>(a, stream);
+    // Latency regime (a few hundred tokens: one utterance): 64 x 64 tiles also for the split-K launches of up to 200
+    // large tiles, and the X image double-buffered, so that the refill at every channel-chunk change (every step of a
+    // k = 1 GEMM) travels with the W prefetch instead of waiting between two barriers of its own: batch-1 forward
+    // (BASELINE config 1) 0.876 -> 0.78 ms with the split-K schedule, -> see DESIGN 5.1 with this.
+    // (X and W in rings of three staged TWO steps ahead behind counted vmcnt waits, 60 KB of LDS: 5-15 % SLOWER per
+    // launch here - decoder first FFN conv of one utterance 22.4 vs 19.7 us, encoder second 15.8 vs 13.6: a step of these
+    // launches is bound by the barrier -> LDS read -> MFMA chain of one wave per SIMD, not by the stage's round trip)
+    if (big_blocks < 64 || (a.M <= 1024 && big_blocks < 200)) return launch_conv_gemm<float, 2, 2, 2, 1, true, 4, 0, true>(a, stream);
     return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
 }
 
@@ -596,7 +603,7 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
     const bool small = big_blocks < 200;   // would leave most of the 256 CUs idle: use 64x64 tiles
     if (!dma) return small ? launch_conv_gemm<T, 2, 2, 2, 0, true, 2>(a, stream) : launch_conv_gemm<T, 4, 4, 2, 0, true, 2>(a, stream);
-    if (small) return launch_conv_gemm<T, 2, 2, 2, 1, false, 4>(a, stream);
+    if (small) return launch_conv_gemm<T, 2, 2, 2, 1, true, 4>(a, stream);      // X double-buffered: see dispatch_conv_gemm_split
     // 128x128 (MT = 4), X image single-buffered: 50 KB of LDS -> 3 workgroups per CU.  Measured on MI355X (config-2
     // decoder FFN, bf16, random data): 128.1 us vs 154 us for the double-buffered-X / 2 WG per CU form,
     // 155 us for the 3-stage ring (MODE 2), 145-180 us for 8-wave 128x128 / 256x128 and 128x64 tiles.
@@ -727,14 +734,42 @@ extern "C" int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype) 
     const int nch = (Cin + (dtype == 1 ? 64 : 32) - 1) / (dtype == 1 ? 64 : 32);
     if (M <= 0 || nch * taps < 32) return 1;
     const long blocks = (long)((M + 127) / 128) * ((N + 127) / 128);
-    static const int cand[6] = {1, 2, 3, 4, 6, 8};
+    static const int cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
     int best = 1;
     double best_cost = 0.0;
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < 8; ++q) {
         const int ks = cand[q];
         if (ks > nch || (ks > 1 && (nch / ks) * taps < 8)) break;
-        const double c = conv_gemm_split_cost(M, N, nch * taps, blocks, ks);
+        // 12 and 16 partials: a handful of tokens only (one short utterance: 2 workgroups would walk 288 steps each), and
+        // only when every K range gets chunks
+        if (ks > 8 && (blocks > 4 || (long)(ks - 1) * ((nch + ks - 1) / ks) >= nch)) continue;
+        // beyond 8 partials the LayerNorm kernel's walk over them shows: + 0.25 us each (profiles/r03_q_*)
+        const double c = conv_gemm_split_cost(M, N, nch * taps, blocks, ks) + (ks > 8 ? 0.25 * (ks - 8) : 0.0);
         if (q == 0 || c < best_cost) { best = ks; best_cost = c; }
+    }
+    return best;
+}
+
+// Split-K for a GEMM whose ACTIVATION must follow the full sum (first FFN conv, predictor convs: ReLU): the launch writes
+// plain partials (bias in partial 0, no activation) and fs2_sum_act_layernorm applies the ReLU to their sum — as part of
+// the LayerNorm that follows anyway (predictors: extra_us = 0) or as one more small launch (first FFN conv: extra_us =
+// its cost, about 3.5 us).  Only the latency regime is served: at most 64 tiles of 128 x 128 (a few hundred tokens: one
+// utterance, batch-1 decoding), where the launch is a few workgroups each walking the whole K range; and only for a
+// modelled gain of 20 % or more.  Returns 1 when the unsplit launch with the ReLU in its epilogue is the path to take.
+extern "C" int fs2_conv_gemm_ksplit_act(int M, int N, int Cin, int taps, int dtype, float extra_us) {
+    const int nch = (Cin + (dtype == 1 ? 64 : 32) - 1) / (dtype == 1 ? 64 : 32);
+    const long blocks = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (M <= 0 || nch * taps < 12 || blocks > 64) return 1;
+    static const int cand[6] = {2, 3, 4, 6, 8, 16};
+    const double base = conv_gemm_split_cost(M, N, nch * taps, blocks, 1);
+    int best = 1;
+    double best_cost = 0.8 * base;
+    for (int q = 0; q < 6; ++q) {
+        const int ks = cand[q];
+        const int cps = (nch + ks - 1) / ks;
+        if (ks > nch || cps * taps < 4 || (long)(ks - 1) * cps >= nch) continue;
+        const double c = conv_gemm_split_cost(M, N, nch * taps, blocks, ks) + extra_us + 0.25 * (ks - 1);
+        if (c < best_cost) { best = ks; best_cost = c; }
     }
     return best;
 }

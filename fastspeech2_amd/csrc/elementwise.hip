@@ -90,7 +90,17 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t[r] += ps[r] * drop_mul(dparts, (uint32_t)row, (uint32_t)(j * 4 + r));
             } else {
-                for (int p = 0; p < nparts; ++p) t += *(const f32x4*)(parts + (size_t)p * part_stride + roff + j * 4);
+                // four loads in flight at a time, added in the order p = 0, 1, 2 ... (the sum is the same, bit for bit)
+                const float* src = parts + roff + j * 4;
+                int p = 0;
+                for (; p + 4 <= nparts; p += 4) {
+                    const f32x4 a0 = *(const f32x4*)(src + (size_t)p * part_stride);
+                    const f32x4 a1 = *(const f32x4*)(src + (size_t)(p + 1) * part_stride);
+                    const f32x4 a2 = *(const f32x4*)(src + (size_t)(p + 2) * part_stride);
+                    const f32x4 a3 = *(const f32x4*)(src + (size_t)(p + 3) * part_stride);
+                    t += a0; t += a1; t += a2; t += a3;
+                }
+                for (; p < nparts; ++p) t += *(const f32x4*)(src + (size_t)p * part_stride);
             }
             v[k] = t;
             if (sum_out) *(f32x4*)(sum_out + roff + j * 4) = t;
@@ -187,6 +197,105 @@ __global__ __launch_bounds__(256) void add_layernorm_rows4_kernel(const float* _
         if (out_f32) *(f32x4*)(out_f32 + roff + c) = o;
         if (out_t) store4<T>(out_t + roff + c, o);
     }
+}
+
+// LayerNorm(act(sum_p parts[p])) -> fp32 and/or T copies; without w / b: act(sum_p parts[p]) alone, in T storage.
+// The consumer of split-K partials of a GEMM whose activation needs the full sum: predictor convs (Conv1d -> ReLU ->
+// LayerNorm, network/variance_adaptor.py:72-75) and the first FFN conv (ReLU, network/encoder.py:28-30) in the latency
+// regime (fs2_conv_gemm_ksplit_act).  One wave per row; the partials are read four at a time (independent loads).
+template <typename T>
+__global__ __launch_bounds__(256) void sum_act_layernorm_kernel(const float* __restrict__ parts, int nparts,
+                                                                long long part_stride, int relu,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ out_f32, T* __restrict__ out_t, int M, int C,
+                                                                float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int cv = C >> 2;
+    const size_t roff = (size_t)row * C;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            const float* src = parts + roff + j * 4;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            int p = 0;
+            for (; p + 4 <= nparts; p += 4) {
+                const f32x4 a0 = *(const f32x4*)(src + (size_t)p * part_stride);
+                const f32x4 a1 = *(const f32x4*)(src + (size_t)(p + 1) * part_stride);
+                const f32x4 a2 = *(const f32x4*)(src + (size_t)(p + 2) * part_stride);
+                const f32x4 a3 = *(const f32x4*)(src + (size_t)(p + 3) * part_stride);
+                t += (a0 + a1) + (a2 + a3);
+            }
+            for (; p < nparts; ++p) t += *(const f32x4*)(src + (size_t)p * part_stride);
+            if (relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = fmaxf(t[r], 0.f);
+            }
+            v[k] = t;
+            if (!w) {
+                if (out_f32) *(f32x4*)(out_f32 + roff + j * 4) = t;
+                if (out_t) store4<T>(out_t + roff + j * 4, t);
+            }
+            s += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+    }
+    if (!w) return;
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dlt = v[k][r] - mean;
+                q += dlt * dlt;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int j = lane + k * 64;
+        if (j < cv) {
+            const f32x4 ww = *(const f32x4*)(w + j * 4);
+            const f32x4 bb = *(const f32x4*)(b + j * 4);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[k][r] - mean) * rstd * ww[r] + bb[r];
+            if (out_f32) *(f32x4*)(out_f32 + roff + j * 4) = o;
+            if (out_t) store4<T>(out_t + roff + j * 4, o);
+        }
+    }
+}
+
+// act(sum_p parts[p]) alone (no LayerNorm): one lane per four channels, up to eight partial loads in flight
+template <typename T>
+__global__ __launch_bounds__(256) void sum_act_kernel(const float* __restrict__ parts, int nparts, long long part_stride, int relu,
+                                                      float* __restrict__ out_f32, T* __restrict__ out_t, long long n4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    const float* src = parts + idx * 4;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {       // same pairing as sum_act_layernorm_kernel
+        const f32x4 a0 = *(const f32x4*)(src + (size_t)p * part_stride);
+        const f32x4 a1 = *(const f32x4*)(src + (size_t)(p + 1) * part_stride);
+        const f32x4 a2 = *(const f32x4*)(src + (size_t)(p + 2) * part_stride);
+        const f32x4 a3 = *(const f32x4*)(src + (size_t)(p + 3) * part_stride);
+        t += (a0 + a1) + (a2 + a3);
+    }
+    for (; p < nparts; ++p) t += *(const f32x4*)(src + (size_t)p * part_stride);
+    if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = fmaxf(t[r], 0.f);
+    }
+    if (out_f32) *(f32x4*)(out_f32 + idx * 4) = t;
+    if (out_t) store4<T>(out_t + idx * 4, t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -773,6 +882,50 @@ extern "C" int fs2_add_layernorm_dropout(const float* x, const float* parts, int
     return add_layernorm_entry(x, parts, nparts, part_stride, w, b, sum_out, out_f32, out_t, M, C, eps, dtype,
                                fs2_make_dropout(seed, parts_stream, parts_rate), fs2_make_dropout(seed, out_stream, out_rate),
                                stream);
+}
+
+extern "C" int fs2_sum_act_layernorm(const float* parts, int nparts, long long part_stride, int relu, const float* w,
+                                     const float* b, float* out_f32, void* out_t, int M, int C, float eps, int dtype,
+                                     hipStream_t stream) {
+    FS2_CHECK_ARG(parts && nparts >= 1 && nparts <= 16 && (nparts == 1 || part_stride >= (long long)M * C) && part_stride % 4 == 0,
+                  "fs2_sum_act_layernorm: bad partial layout");
+    FS2_CHECK_ARG((w != nullptr) == (b != nullptr) && (out_f32 || out_t), "fs2_sum_act_layernorm: w / b go together; nothing to write");
+    FS2_CHECK_ARG(relu == 0 || relu == 1, "fs2_sum_act_layernorm: activation code %d (0 none, 1 relu)", relu);
+    FS2_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "fs2_sum_act_layernorm: C=%d unsupported (multiple of 4, <= %d)",
+                  C, 256 * LN_MAXV);
+    FS2_CHECK_ARG(dtype >= 0 && dtype <= 2, "fs2_sum_act_layernorm: dtype=%d", dtype);
+    FS2_CHECK_ARG(dtype != 2 || !out_t || (C % 32 == 0 && ((uintptr_t)out_t & 127) == 0),
+                  "fs2_sum_act_layernorm(f16x3): C=%d must be a multiple of 32 and out_t 128-byte aligned", C);
+    FS2_CHECK_ARG(((uintptr_t)parts & 15) == 0 && ((uintptr_t)out_f32 & 15) == 0 && ((uintptr_t)out_t & 7) == 0 &&
+                      ((uintptr_t)w & 15) == 0 && ((uintptr_t)b & 15) == 0, "fs2_sum_act_layernorm: alignment");
+    if (M <= 0) return FS2_OK;
+    if (!w) {
+        const long long n4 = (long long)M * (C / 4);
+        const dim3 ge(blocks_for(n4, 256));
+        if (dtype == 2)
+            hipLaunchKernelGGL(sum_act_kernel<f16pair_t>, ge, dim3(256), 0, stream, parts, nparts, part_stride, relu, out_f32,
+                               (f16pair_t*)out_t, n4);
+        else if (dtype == 1)
+            hipLaunchKernelGGL(sum_act_kernel<bf16_t>, ge, dim3(256), 0, stream, parts, nparts, part_stride, relu, out_f32,
+                               (bf16_t*)out_t, n4);
+        else
+            hipLaunchKernelGGL(sum_act_kernel<float>, ge, dim3(256), 0, stream, parts, nparts, part_stride, relu, out_f32,
+                               (float*)out_t, n4);
+        FS2_CHECK_LAUNCH("fs2_sum_act_layernorm");
+        return FS2_OK;
+    }
+    const dim3 g(blocks_for(M, 4));
+    if (dtype == 2)
+        hipLaunchKernelGGL(sum_act_layernorm_kernel<f16pair_t>, g, dim3(256), 0, stream, parts, nparts, part_stride, relu, w, b,
+                           out_f32, (f16pair_t*)out_t, M, C, eps);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(sum_act_layernorm_kernel<bf16_t>, g, dim3(256), 0, stream, parts, nparts, part_stride, relu, w, b,
+                           out_f32, (bf16_t*)out_t, M, C, eps);
+    else
+        hipLaunchKernelGGL(sum_act_layernorm_kernel<float>, g, dim3(256), 0, stream, parts, nparts, part_stride, relu, w, b,
+                           out_f32, (float*)out_t, M, C, eps);
+    FS2_CHECK_LAUNCH("fs2_sum_act_layernorm");
+    return FS2_OK;
 }
 
 extern "C" int fs2_dropout(float* x, void* out_t, int M, int C, unsigned seed, unsigned stream_id, float rate, int dtype,

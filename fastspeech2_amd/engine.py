@@ -160,6 +160,8 @@ class Engine:
     statistics with the GEMMs on error-compensated fp16 operands (fs2_conv_gemm_f16x3: fp32-grade durations at about
     a fifth of the exact-fp32 MFMA time)."""
 
+    SMALL_FRAMES = 4096      # frame phases up to this many frames take the latency schedule (Engine.latency_split)
+
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, dtype: str = "fp32",
                  encoder_dtype: Optional[str] = None, device=None):
         self.dev = torch.device(device) if device is not None else hip.require_gpu()
@@ -241,6 +243,8 @@ class Engine:
         self.reg_w = False             # True: fs2_gemm_regw for the q | k | v projection of big batches (21.3 vs 22.8 us alone,
                                        # no difference in the overlapped step: bench.py --engine-set reg_w=1)
         self.fused_proj_ln = True      # post-LN blocks at d = 256, bf16: output projection + residual + norm1 as one kernel (csrc/proj_ln.hip)
+        self._aux = None               # second stream of the latency schedule (frame_phase)
+        self.latency_split = True      # a few hundred tokens: ReLU convs run split-K, fs2_sum_act_layernorm applies the ReLU to the sum
         self.split_attention = True    # f16x3 phone-level half: attention on split-fp16 q | k | v (False: fp32 q | k | v, exact-fp32 MFMA)
         self.big_tiles = True          # fs2_conv_gemm256 where fs2_conv_gemm256_plan picks it (False: fs2_conv_gemm always)
         self._pe = None
@@ -275,6 +279,18 @@ class Engine:
                   split=False):
         """One FFN conv (network/encoder.py:28-30): on fs2_conv_gemm256 where it serves the shape and the batch is big
         enough (it decides its own number of K ranges), else on fs2_conv_gemm.  split: the caller sums fp32 partials."""
+        if relu and not out_f32 and res is None and not split and self.latency_split and N <= 1024:
+            # a few hundred tokens (one utterance): the unsplit launch is a handful of workgroups walking the whole K range
+            # one after the other; split-K partials + one small ReLU pass over their sum are shorter (the rule sits beside
+            # the kernel dispatch: fs2_conv_gemm_ksplit_act)
+            ks = int(hip.load().fs2_conv_gemm_ksplit_act(int(M), int(N), int(Cin), int(taps), int(code), 3.5))
+            if ks > 1:
+                parts = self._gemm(x, L[which], L["b" + which[1]], M, N, Cin, taps, code, seg=seg, out_f32=True, tag=tag,
+                                   ksplit=ks)
+                out = self._empty((M, N), code)
+                call("fs2_sum_act_layernorm", ptr(parts), ks, M * N, 1, None, None, None, ptr(out), M, N, LN_EPS, code,
+                     stream())
+                return out
         wt = L.get(which + "_tiled")
         ks = 0
         if wt is not None and self.big_tiles and seg is not None:
@@ -416,9 +432,21 @@ class Engine:
         n = len(pr.convs)
         y32 = None
         for j, c in enumerate(pr.convs):
+            last = j == n - 1
+            ks = 1
+            if self.latency_split and not (last and fuse_head) and c["chans"] <= 1024:
+                ks = int(hip.load().fs2_conv_gemm_ksplit_act(int(M), int(c["chans"]), int(cin), int(c["taps"]), int(code), 0.0))
+            if ks > 1:      # latency regime: split-K partials, the ReLU moves into the LayerNorm kernel that sums them
+                y = self._gemm(cur, c["w"], c["b"], M, c["chans"], cin, c["taps"], code,
+                               seg=seg if c["taps"] > 1 else None, out_f32=True, ksplit=ks)
+                y32 = self._empty((M, c["chans"]), dtype=torch.float32) if (last or code == F32) else None
+                cur = y32 if code == F32 else (None if last else self._empty((M, c["chans"]), code))
+                call("fs2_sum_act_layernorm", ptr(y), ks, M * c["chans"], 1, ptr(c["ln_w"]), ptr(c["ln_b"]), ptr(y32),
+                     ptr(cur) if code != F32 else None, M, c["chans"], LN_EPS, code, stream())
+                cin = c["chans"]
+                continue
             y = self._gemm(cur, c["w"], c["b"], M, c["chans"], cin, c["taps"], code,
                            seg=seg if c["taps"] > 1 else None, relu=True, out_f32=True)
-            last = j == n - 1
             if last and fuse_head:
                 # last LayerNorm + head in one pass over the conv output (the LayerNorm output is not stored)
                 out = self._empty((M, pr.nout), dtype=torch.float32)
@@ -556,8 +584,28 @@ class Engine:
                  ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
         if dc == F32:
             hs_lrt = hs_lr32
-        pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
-        energy = self._predict(self.energy_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
+        if self.latency_split and 0 < Mf <= self.SMALL_FRAMES and self.profile is None:
+            # a few thousand frames: each predictor launch fills a fraction of the CUs, and the two predictors are
+            # independent (network/variance_adaptor.py:190-197) - the energy predictor runs on a second stream beside the
+            # pitch predictor (fork / join by events, also under graph capture)
+            cur = torch.cuda.current_stream()
+            if self._aux is None:
+                self._aux = torch.cuda.Stream(device=self.dev)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            self._aux.wait_event(fork)
+            with torch.cuda.stream(self._aux):
+                energy = self._predict(self.energy_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
+                join = torch.cuda.Event()
+                join.record(self._aux)
+            pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
+            cur.wait_event(join)
+            hs_lrt.record_stream(self._aux)
+            seg_f.record_stream(self._aux)
+            energy.record_stream(cur)
+        else:
+            pitch = self._predict(self.pitch_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
+            energy = self._predict(self.energy_pred, hs_lrt, seg_f, Mf, d, fuse_head=True)
         p_in = pitch if ps is None else ps.to(dev, torch.float32).contiguous()
         e_in = energy if es is None else es.to(dev, torch.float32).contiguous()
         pscale = float(pitch_control) if ps is None else 1.0

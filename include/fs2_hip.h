@@ -152,6 +152,19 @@ int fs2_proj_add_layernorm_plan(int M, int N, int Cin, int dtype);
  * the reference (it is part of the kernel dispatch). */
 int fs2_conv_gemm_ksplit(int M, int N, int Cin, int taps, int dtype);
 
+/* The same for a GEMM whose activation needs the full sum (ReLU of the first FFN conv, network/encoder.py:28-30, and of
+ * the predictor convs, network/variance_adaptor.py:72-75): the launch then runs with `relu` = 0 and `ksplit` partials and
+ * fs2_sum_act_layernorm applies the ReLU to their sum.  extra_us: cost of that call when it is an extra launch (0 where
+ * a LayerNorm follows anyway).  Serves the latency regime only (one utterance, batch-1 decoding); 1 = do not split. */
+int fs2_conv_gemm_ksplit_act(int M, int N, int Cin, int taps, int dtype, float extra_us);
+
+/* LayerNorm(act(sum_p parts[p])) -> fp32 and/or T copies [M, C]; with w = b = NULL: act(sum_p parts[p]) alone.
+ * parts fp32 [nparts][part_stride] (split-K partials of fs2_conv_gemm, bias in partial 0), relu: 0 none, 1 ReLU.
+ * Conv1d -> ReLU -> LayerNorm of the predictors (network/variance_adaptor.py:72-75, :108-111) and the ReLU between the
+ * FFN convs (network/encoder.py:28-30) when the conv ran split-K.  C % 4 == 0, C <= 1024, nparts <= 16. */
+int fs2_sum_act_layernorm(const float* parts, int nparts, long long part_stride, int relu, const float* w, const float* b,
+                          float* out_f32, void* out_t, int M, int C, float eps, int dtype, hipStream_t stream);
+
 /* Fused varlen multi-head self-attention (scores, softmax, P.V) over packed qkv [M, ld] T laid out
  * q | k | v with each part [n_heads][dk]; ctx [M, ldo] T.  dk in {32, 64, 96, 128}.
  * dtype 2 (FS2_F16X3): fp32 q | k | v and fp32 arithmetic, ctx written in split-fp16 storage (the operand form of

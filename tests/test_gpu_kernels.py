@@ -309,6 +309,92 @@ def test_conv_gemm_splitk_then_add_layernorm(dtype, taps, cin, n, lens, ksplit):
     assert (ot.float().cpu().double() - ref).abs().max().item() <= (tol if dtype == "fp32" else 5e-2)
 
 
+def test_conv_gemm_ksplit_act_rule():
+    """Split-K for ReLU convs is a latency-regime tool only: one utterance's worth of tokens, never a batch."""
+    ks = hip.load().fs2_conv_gemm_ksplit_act
+    assert ks(120, 1024, 256, 9, 2, 3.5) >= 4         # encoder first FFN conv of one utterance: 32 workgroups x 72 steps
+    assert ks(120, 256, 256, 3, 2, 0.0) >= 2          # duration predictor conv, 8 workgroups x 24 steps
+    assert ks(3767, 1024, 256, 9, 2, 3.5) == 1        # bench batch, phone level
+    assert ks(25611, 1024, 256, 9, 1, 3.5) == 1       # bench batch, frame level
+    assert ks(25611, 384, 256, 3, 1, 0.0) == 1
+    assert ks(120, 64, 32, 3, 0, 0.0) == 1            # tiny K: nothing to split
+    assert ks(0, 1024, 256, 9, 1, 3.5) == 1
+    for M in (1, 60, 120, 450, 810, 3100):
+        for N, C, t in [(1024, 256, 9), (256, 256, 3), (384, 384, 3), (1536, 384, 1)]:
+            for code in (0, 1, 2):
+                k = ks(M, N, C, t, code, 3.5)
+                nch = -(-C // (64 if code == 1 else 32))
+                assert 1 <= k <= 16 and (k == 1 or (k - 1) * (-(-nch // k)) < nch)      # every K range owns chunks
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "f16x3"])
+@pytest.mark.parametrize("taps,cin,n,lens,ksplit,with_ln", [(9, 256, 1024, [120], 8, False), (3, 256, 256, [97, 23], 4, True),
+                                                            (3, 384, 384, [810], 3, True), (9, 256, 1024, [5, 1], 16, False)])
+def test_splitk_relu_conv_through_sum_act_layernorm(dtype, taps, cin, n, lens, ksplit, with_ln):
+    """Conv1d -> ReLU (-> LayerNorm) with the conv run split-K and the ReLU applied to the sum of the partials by
+    fs2_sum_act_layernorm (network/encoder.py:28-30, network/variance_adaptor.py:72-75), against the unsplit launch with
+    the ReLU in its epilogue (+ fs2_layernorm): same numbers up to the order of the fp32 K sum."""
+    code = {"fp32": hip.F32, "bf16": hip.BF16, "f16x3": hip.F16X3}[dtype]
+    if code == hip.F16X3 and ksplit > cin // 32:
+        pytest.skip("more K ranges than 32-channel runs")
+    if code == hip.BF16 and ksplit > cin // 64:
+        ksplit = cin // 64
+    g = torch.Generator().manual_seed(taps * 31 + cin + n + ksplit)
+    M = sum(lens)
+    x = torch.randn(M, cin, generator=g)
+    w = torch.randn(n, cin, taps, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(n, generator=g) * 0.1
+    lw, lb = torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    _, _, seg, _ = _seg_tables(lens)
+    sg = ptr(seg) if taps > 1 else None
+    from fastspeech2_amd.engine import pack_gemm_weight
+    tdt = hip.TORCH_DTYPE[code]
+    xd = torch.empty((M, cin), device=DEV, dtype=tdt)
+    call("fs2_cast", ptr(x.to(DEV).contiguous()), ptr(xd), M * cin, code, stream())
+    wd = pack_gemm_weight(w.to(DEV), code)
+    bd = b.to(DEV)
+
+    def conv(out, relu, ks):
+        if code == hip.F16X3:
+            call("fs2_conv_gemm_f16x3", ptr(xd), ptr(wd), wd.fs2_scale, ptr(bd), None, ptr(out), sg, M, n, cin, taps, cin, n,
+                 n, relu, 1, ks, M * n, stream())
+        else:
+            call("fs2_conv_gemm", ptr(xd), ptr(wd), ptr(bd), None, ptr(out), sg, M, n, cin, taps, cin, n, n, relu, 1, code, ks,
+                 M * n, stream())
+    whole = torch.full((M, n), float("nan"), device=DEV)
+    conv(whole, 1, 1)
+    parts = torch.full((ksplit, M, n), float("nan"), device=DEV)
+    conv(parts, 0, ksplit)
+    o32 = torch.full((M, n), float("nan"), device=DEV)
+    ot = torch.zeros((M, n), device=DEV, dtype=tdt)
+    e32 = torch.empty((M, n), device=DEV)
+    et = torch.zeros((M, n), device=DEV, dtype=tdt)
+    if with_ln:
+        call("fs2_sum_act_layernorm", ptr(parts), ksplit, M * n, 1, ptr(lw), ptr(lb), ptr(o32), ptr(ot) if code else None, M, n,
+             1e-12, code, stream())
+        call("fs2_layernorm", ptr(whole), ptr(lw), ptr(lb), ptr(e32), ptr(et) if code else None, M, n, 1e-12, code, stream())
+    else:
+        call("fs2_sum_act_layernorm", ptr(parts), ksplit, M * n, 1, None, None, ptr(o32), ptr(ot) if code else None, M, n,
+             1e-12, code, stream())
+        e32 = whole
+        call("fs2_cast", ptr(whole), ptr(et), M * n, code, stream())
+    big = max(1.0, e32.abs().max().item())
+    assert torch.isfinite(o32).all()
+    assert (o32 - e32).abs().max().item() <= 2e-5 * big
+    if code == hip.BF16:        # a bf16 copy may land on the neighbouring value where the fp32 sums differ in the last bits
+        assert (ot.float() - et.float()).abs().max().item() <= 2 ** -7 * big
+    elif code == hip.F16X3:     # split-fp16 storage: hi + lo gives the fp32 value back
+        def joined(t):
+            h = t.cpu().view(torch.float16).view(M, n // 32, 2, 32).float()
+            return (h[:, :, 0] + h[:, :, 1]).reshape(M, n)
+        assert (joined(ot) - o32.cpu()).abs().max().item() <= 4e-6 * big
+        assert (joined(ot) - joined(et)).abs().max().item() <= 2e-5 * big
+    # no activation: the plain sum of the partials
+    s32 = torch.empty((M, n), device=DEV)
+    call("fs2_sum_act_layernorm", ptr(parts), ksplit, M * n, 0, None, None, ptr(s32), None, M, n, 1e-12, hip.F32, stream())
+    assert (s32 - parts.sum(0)).abs().max().item() <= 1e-5 * big
+
+
 @pytest.mark.parametrize("C", [64, 256, 384, 1024])
 def test_layernorm(C):
     g = torch.Generator().manual_seed(C)

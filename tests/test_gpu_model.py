@@ -245,6 +245,40 @@ def test_f16x3_encoder_durations_equal_the_fp32_engine_on_the_bench_batch():
     assert worst <= 5e-6, worst          # fp32 summation-order noise level (measured 1e-6; bf16 encoder: 4e-3)
 
 
+@pytest.mark.parametrize("n_phones", [120, 37, 450])
+def test_single_utterance_latency_schedule_equals_the_batch_schedule(n_phones):
+    """BASELINE config 1 (one utterance): with a few hundred tokens the engine runs the ReLU convs split-K and applies
+    the ReLU to the summed partials (Engine.latency_split, fs2_conv_gemm_ksplit_act / fs2_sum_act_layernorm).  Same
+    durations as the schedule without it and as the CPU oracle; log-durations to fp32 summation noise; mel to the bf16
+    tolerance against the oracle."""
+    from fastspeech2_amd import synth
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = synth.bench_state_dict()
+    ids = torch.from_numpy(np.random.Generator(np.random.PCG64(n_phones)).integers(1, synth.BENCH_IDIM, size=n_phones))
+    model = FeedForwardTransformer(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval().cuda().set_precision("bf16", "f16x3")
+    from fastspeech2_amd import hip
+    eng = model.engine()
+    assert eng.latency_split
+    assert hip.load().fs2_conv_gemm_ksplit_act(n_phones, 1024, 256, 9, hip.F16X3, 3.5) > 1      # the path under test is taken
+    res = {}
+    for on in (True, False):
+        eng.latency_split = on
+        pk = model.infer_batch([ids])["packed"]
+        res[on] = (pk["durations_pred"].cpu().numpy(), pk["log_durations"].cpu().numpy(), pk["mel"].float().cpu().numpy())
+    eng.latency_split = True
+    assert np.array_equal(res[True][0], res[False][0])
+    assert np.abs(res[True][1] - res[False][1]).max() <= 5e-6
+    assert res[True][2].shape == res[False][2].shape
+    cfg = fs2_oracle.full_cfg(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
+    o = fs2_oracle.infer_one({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, ids)
+    assert np.array_equal(res[True][0], o["durations"].numpy())
+    assert np.abs(res[True][1] - o["log_durations"].numpy()).max() <= 5e-6
+    for on in (True, False):
+        assert np.abs(res[on][2] - o["mel"].numpy()).max() <= BF16_MEL_TOL, on
+
+
 @pytest.mark.parametrize("variant", ["small_ln_outputs", "large_ffn_hidden"])
 def test_f16x3_encoder_on_rescaled_weights(variant):
     """The f16x3 mode splits activations UNSCALED into fp16 pairs (include/fs2_hip.h): operands far from 1 lose low-half
