@@ -268,12 +268,30 @@ class Engine:
     def _empty(self, shape, code=None, dtype=None):
         return torch.empty(shape, device=self.dev, dtype=dtype or hip.TORCH_DTYPE[code])
 
-    @staticmethod
-    def _ksplit(M, N, Cin, taps, code):
+    _plan_cache: Dict[tuple, int] = {}
+
+    @classmethod
+    def _plan(cls, name, *args):
+        """A dispatch query of the library (fs2_*_plan / fs2_conv_gemm_ksplit*: pure functions of the shape), memoised -
+        a ctypes call per GEMM shows in the host-bound batch-1 forward."""
+        key = (name,) + args
+        v = cls._plan_cache.get(key)
+        if v is None:
+            if len(cls._plan_cache) > 65536:
+                cls._plan_cache.clear()
+            v = cls._plan_cache[key] = int(getattr(hip.load(), name)(*args))
+        return v
+
+    @classmethod
+    def _ksplit_act(cls, M, N, Cin, taps, code, extra_us):
+        return cls._plan("fs2_conv_gemm_ksplit_act", int(M), int(N), int(Cin), int(taps), int(code), float(extra_us))
+
+    @classmethod
+    def _ksplit(cls, M, N, Cin, taps, code):
         """Split-K factor for a GEMM whose tiling would leave most CUs idle (phone-level stacks, batch-1
         decoding, the narrow second FFN conv).  Only used where an add+LayerNorm kernel consumes the partials.
         The rule lives beside the kernel dispatch (csrc/conv_gemm.hip: fs2_conv_gemm_ksplit)."""
-        return int(hip.load().fs2_conv_gemm_ksplit(int(M), int(N), int(Cin), int(taps), int(code)))
+        return cls._plan("fs2_conv_gemm_ksplit", int(M), int(N), int(Cin), int(taps), int(code))
 
     def _ffn_conv(self, x, L, which, M, N, Cin, taps, code, seg, res=None, relu=False, out_f32=False, tag=None,
                   split=False):
@@ -283,7 +301,7 @@ class Engine:
             # a few hundred tokens (one utterance): the unsplit launch is a handful of workgroups walking the whole K range
             # one after the other; split-K partials + one small ReLU pass over their sum are shorter (the rule sits beside
             # the kernel dispatch: fs2_conv_gemm_ksplit_act)
-            ks = int(hip.load().fs2_conv_gemm_ksplit_act(int(M), int(N), int(Cin), int(taps), int(code), 3.5))
+            ks = self._ksplit_act(M, N, Cin, taps, code, 3.5) if M <= 8192 else 1
             if ks > 1:
                 parts = self._gemm(x, L[which], L["b" + which[1]], M, N, Cin, taps, code, seg=seg, out_f32=True, tag=tag,
                                    ksplit=ks)
@@ -294,7 +312,7 @@ class Engine:
         wt = L.get(which + "_tiled")
         ks = 0
         if wt is not None and self.big_tiles and seg is not None:
-            ks = int(hip.load().fs2_conv_gemm256_plan(int(M), int(N), int(Cin), int(taps), int(code), 1 if split else 0))
+            ks = self._plan("fs2_conv_gemm256_plan", int(M), int(N), int(Cin), int(taps), int(code), 1 if split else 0)
         if ks < 1:
             return self._gemm(x, L[which], L["b" + which[1]], M, N, Cin, taps, code, seg=seg, res=res, relu=relu,
                               out_f32=out_f32, tag=tag, ksplit=self._ksplit(M, N, Cin, taps, code) if split else 1)
@@ -321,8 +339,8 @@ class Engine:
         nbytes = M * Cin * esz + taps * N * Cin * esz + ksplit * M * N * (4.0 if out_f32 else esz) + (M * N * 4.0 if res is not None else 0.0)
         with self._timed(tag, "flop", 2.0 * M * N * Cin * taps, nbytes):
             if (wscale is None and taps == 1 and ksplit == 1 and out.dim() == 2 and self.reg_w and
-                    hip.load().fs2_gemm_regw_plan(int(M), int(N), int(Cin), int(code), int(res is not None), int(relu),
-                                                  int(out_f32))):
+                    self._plan("fs2_gemm_regw_plan", int(M), int(N), int(Cin), int(code), int(res is not None), int(relu),
+                               int(out_f32))):
                 call("fs2_gemm_regw", ptr(x), ptr(w), ptr(bias), ptr(out), M, N, Cin, Cin, N, int(out_f32), code, stream())
             elif wscale is not None:          # split-fp16 operands (pack_gemm_weight / T copies of code F16X3)
                 assert code == hip.F16X3 and int(relu) in (0, 1)
@@ -387,7 +405,7 @@ class Engine:
                 self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, out_f32=True, out=pend[0], res=x32)
                 self._gemm(att, L["wc_a"], None, M, d, d, 1, code, out_f32=True, out=pend[1])
             elif (not st.pre_ln and self.fused_proj_ln and
-                  hip.load().fs2_proj_add_layernorm_plan(int(M), int(d), int(d), int(code))):
+                  self._plan("fs2_proj_add_layernorm_plan", int(M), int(d), int(d), int(code))):
                 # post-LN block, d = 256, bf16: norm1(x + linear_out(ctx)) as ONE stream over the rows (csrc/proj_ln.hip)
                 n32, nt_ = self._empty((M, d), dtype=torch.float32), self._empty((M, d), code)
                 with self._timed("proj_ln", "byte", M * d * (2.0 + 4.0 + 4.0 + 2.0) + d * d * 2.0):
@@ -434,8 +452,8 @@ class Engine:
         for j, c in enumerate(pr.convs):
             last = j == n - 1
             ks = 1
-            if self.latency_split and not (last and fuse_head) and c["chans"] <= 1024:
-                ks = int(hip.load().fs2_conv_gemm_ksplit_act(int(M), int(c["chans"]), int(cin), int(c["taps"]), int(code), 0.0))
+            if self.latency_split and M <= 8192 and not (last and fuse_head) and c["chans"] <= 1024:
+                ks = self._ksplit_act(M, c["chans"], cin, c["taps"], code, 0.0)
             if ks > 1:      # latency regime: split-K partials, the ReLU moves into the LayerNorm kernel that sums them
                 y = self._gemm(cur, c["w"], c["b"], M, c["chans"], cin, c["taps"], code,
                                seg=seg if c["taps"] > 1 else None, out_f32=True, ksplit=ks)
@@ -584,10 +602,12 @@ class Engine:
                  ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
         if dc == F32:
             hs_lrt = hs_lr32
-        if self.latency_split and 0 < Mf <= self.SMALL_FRAMES and self.profile is None:
+        if (self.latency_split and 0 < Mf <= self.SMALL_FRAMES and self.profile is None and
+                torch.cuda.is_current_stream_capturing()):
             # a few thousand frames: each predictor launch fills a fraction of the CUs, and the two predictors are
             # independent (network/variance_adaptor.py:190-197) - the energy predictor runs on a second stream beside the
-            # pitch predictor (fork / join by events, also under graph capture)
+            # pitch predictor (fork / join by events).  Under graph capture only (GraphedInference): issued launch by
+            # launch from Python the forward is bound by the host, and the fork / join would only add to that.
             cur = torch.cuda.current_stream()
             if self._aux is None:
                 self._aux = torch.cuda.Stream(device=self.dev)
