@@ -293,6 +293,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_kernel(AttnArgs a) {
 // workgroups of a launch then last half as long and there are more of them than CUs, so that utterances of different
 // length balance over the chip (with G = 1 every workgroup is resident from the start and the longest utterance sets
 // the time), and a single long utterance fills twice the SIMDs.
+// G = 4, NW = 2, KB = 1 (512 threads, 64 queries, four key groups of two waves on 32-key tiles, 128 KB of LDS): one
+// utterance alone (batch-1 decoding).  A wave's trip over a key tile is a serial chain (K reads, MFMAs, softmax, V^T
+// reads, MFMAs: ~2.8 us per 64-key trip at one wave per SIMD) and the launch lasts as long as the longest chain:
+// four groups on half-size tiles cut the chain of an 810-frame utterance from 7 trips of 64 keys to 7 of 32, and
+// twice the workgroups stand on the chip.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ f32x16 mma32(const bf16x8& a, const bf16x8& b, f32x16 c) {
@@ -331,7 +336,7 @@ __device__ __forceinline__ void lds_tr_wait(bf16x4 (&v)[4]) {
 // CU): the same tile code on half the keys per trip, i.e. twice the work items of half the size; launch_attention uses
 // it for short utterances (measurements there and in DESIGN.md section 4.2).
 template <int DK, bool DROP, int G, int NW = 4, int KB = 2>
-__global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * NW * G, G == 1 ? 2 : 1) void attention32_kernel(AttnArgs a) {
     typedef bf16_t T;
     constexpr int BKT = 32 * KB;                     // keys per tile
     constexpr int ROWB = DK * 2;                     // bytes per K/V row
@@ -344,8 +349,9 @@ __global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArg
     constexpr bool POW2 = (NS & (NS - 1)) == 0;
     constexpr int BQ = 32 * NW;                      // queries per workgroup
     static_assert(PIECES % NW == 0, "one DMA piece per wave and step");
-    static_assert(G == 1 || (NW == 4 && KB == 2), "two key groups: four waves per group, 64-key tiles");
-    static_assert(G == 1 || 8 * TILE_BYTES >= 4 * 64 * (16 * DB + 2) * 4, "the merge buffer reuses the K/V rings");
+    static_assert(G == 1 || (G == 2 && NW == 4 && KB == 2) || (G == 4 && NW == 2 && KB == 1),
+                  "key groups: two of four waves on 64-key tiles, or four of two waves on 32-key tiles (512 threads)");
+    static_assert(G == 1 || G * 4 * TILE_BYTES >= (G - 1) * NW * 64 * (16 * DB + 2) * 4, "the merge buffer reuses the K/V rings");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // per key group: K ring at {0, 1} * TILE_BYTES, V ring at {2, 3} * TILE_BYTES of its 4 * TILE_BYTES
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArg
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = G == 1 ? wave8 : (wave8 & 3), grp = G == 1 ? 0 : (wave8 >> 2);    // wave within its key group, key group
+    const int wave = G == 1 ? wave8 : (wave8 % NW), grp = G == 1 ? 0 : (wave8 / NW);   // wave within its key group, key group
     const int hi = lane >> 5, lo = lane & 31;
     const T* __restrict__ base = (const T*)a.qkv + (size_t)r0 * a.ld;
     const int qcol = h * DK, kcol = a.d + h * DK, vcol = 2 * a.d + h * DK;
@@ -584,12 +590,14 @@ __global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArg
     }
 
     float l = halves_sum(l_part);
-    if constexpr (G == 2) {
-        // merge of the two key groups: group 1 leaves (O, m, l) in LDS in its own register / lane order, the wave of
-        // group 0 with the same queries (same wave index, same lanes) folds them in
+    if constexpr (G > 1) {
+        // merge of the key groups: groups 1 .. G - 1 leave (O, m, l) in LDS in their own register / lane order, the wave
+        // of group 0 with the same queries (same wave index, same lanes) folds them in, in group order.  (A group without
+        // tiles - fewer tiles than groups - leaves m = -inf, l = 0, O = 0: its factor is exp2(-inf) = 0.)
+        constexpr int MBW = (16 * DB + 2) * 64;      // floats per wave
         __syncthreads();
-        float* mb = (float*)smem + wave * (16 * DB + 2) * 64 + lane;
-        if (grp == 1) {
+        if (grp > 0) {
+            float* mb = (float*)smem + ((grp - 1) * NW + wave) * MBW + lane;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -598,16 +606,20 @@ __global__ __launch_bounds__(64 * NW * G, 2 / G) void attention32_kernel(AttnArg
             mb[(16 * DB + 1) * 64] = l;
         }
         __syncthreads();
-        if (grp == 1) return;
-        const float m_b = mb[(16 * DB) * 64], l_b = mb[(16 * DB + 1) * 64];
-        const float m_new = fmaxf(m_run, m_b);                       // group 0 always has a tile: finite
-        const float fa = __builtin_amdgcn_exp2f(m_run - m_new), fb = __builtin_amdgcn_exp2f(m_b - m_new);
-        m_run = m_new;
-        l = l * fa + l_b * fb;
+        if (grp > 0) return;
+#pragma unroll 1
+        for (int gsrc = 1; gsrc < G; ++gsrc) {     // (rolled: unrolled, the loads of all groups are hoisted and spill)
+            const float* mb = (const float*)smem + ((gsrc - 1) * NW + wave) * MBW + lane;
+            const float m_b = mb[(16 * DB) * 64], l_b = mb[(16 * DB + 1) * 64];
+            const float m_new = fmaxf(m_run, m_b);                       // group 0 always has a tile: finite
+            const float fa = __builtin_amdgcn_exp2f(m_run - m_new), fb = __builtin_amdgcn_exp2f(m_b - m_new);
+            m_run = m_new;
+            l = l * fa + l_b * fb;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] = o[db][r] * fa + mb[(db * 16 + r) * 64] * fb;
+                for (int r = 0; r < 16; ++r) o[db][r] = o[db][r] * fa + mb[(db * 16 + r) * 64] * fb;
+        }
     }
     const float inv = 1.0f / l;
     if (qrow < len) {
@@ -917,6 +929,22 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
             // two key groups per workgroup when one-group workgroups would leave CUs empty (measured: 66 workgroups,
             // config 4 B = 1, 86 -> 71 us; 264 or 448 workgroups are 10 % faster with one group, two per CU)
             const long items = (long)B * H * ((max_len + 127) / 128);
+            const long items64 = (long)B * H * ((max_len + 63) / 64);
+            // four key groups (64-query workgroups) while those still stand on the chip one per CU: a single utterance
+            const bool four = groups ? groups == 4 : (max_len > 4 * AT_BK && items64 <= 256 && !aa.drop.thresh);
+            if (four) {
+                static unsigned long long ok4 = 0;
+                const void* k4 = (const void*)attention32_kernel<DK, false, 4, 2, 1>;
+                const int lds4 = 4 * (lds / 2);
+                fs2_allow_lds(k4, lds4, &ok4);
+                const dim3 grid4 = fs2_pair_order_grid(aa.order, (max_len + 63) / 64, H, B, xcd_on != 0);
+                void* params[] = {&aa};
+                if (hipLaunchKernel(k4, grid4, dim3(512), params, lds4, stream) != hipSuccess) {
+                    fs2_set_error("fs2_attention: launch failed: %s", hipGetErrorString(hipGetLastError()));
+                    return FS2_ERR_HIP;
+                }
+                return FS2_OK;
+            }
             const bool two = groups ? groups == 2 : (max_len > 4 * AT_BK && items <= 256);
             // 64-query workgroups on 32-key tiles for short utterances (phone level: <= 256 keys, i.e. one or two
             // 128-query items per pair): twice the workgroups of half the size, 9.0 -> 7.7 us at 32 x ~120 phones.  At

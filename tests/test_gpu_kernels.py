@@ -674,7 +674,9 @@ def test_attention_on_split_fp16_operands_is_fp32_grade(h, dk, lens):
 @pytest.mark.parametrize("h,dk,lens", [(2, 32, [1, 70, 5]), (2, 64, [129, 64]), (4, 96, [33, 200]), (2, 128, [300, 17, 64]),
                                        (2, 128, [120, 64, 33, 256]),      # <= 256 keys: the 64-query / 32-key-tile form at dk 128
                                        (2, 64, [130, 64, 257, 1, 90]),    # 10 pairs: XCD-aware order with a padded grid
-                                       (2, 128, [130, 4165, 3000])])      # BASELINE config 4: ~4000-frame decoder rows
+                                       (2, 128, [130, 4165, 3000]),       # BASELINE config 4: ~4000-frame decoder rows
+                                       (2, 128, [810]), (2, 128, [3138]), (2, 64, [257]),     # one utterance: four key groups (bf16)
+                                       (4, 32, [1500, 3, 70])])
 def test_attention(dtype, h, dk, lens):
     code = hip.DTYPE_CODE[dtype]
     tdt = hip.TORCH_DTYPE[code]

@@ -15,6 +15,7 @@ _fix = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 cases = [("bench.py batch", np.load(_fix)["frames"].astype(int).tolist()),     # the frame counts of bench.py's own batch
          ("config 2 decoder", np.clip(np.rint(rng.normal(800, 100, 32)), 400, 1200).astype(int).tolist()),
          ("config 2 encoder", np.clip(np.rint(rng.normal(120, 15, 32)), 60, 180).astype(int).tolist()),
+         ("config 1 B=1", [810]), ("one of 1600", [1600]), ("config 4 B=1 (512 ph)", [3138]),
          ("config 4 B=1", [4165]), ("config 4 B=4", [4165, 4100, 3900, 4000]),
          ("uniform 64 x 1024", [1024] * 64)]      # no imbalance: the tile code's own rate
 order = os.environ.get("FS2_BENCH_SORT", "")      # "desc" / "asc": utterances sorted by length (decode() hands over descending)
