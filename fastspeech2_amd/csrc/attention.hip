@@ -982,7 +982,11 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
 template <int DK>
 static int launch_attention_split(const AttnArgs& a, int B, int H, int max_len, hipStream_t stream) {
     // 32-key tiles: 64 KB of LDS at dk = 128 (two workgroups per CU, and room for another stream's workgroups beside one)
-    static const int bk = FS2_ENV_INT("FS2_ATTN_SPLIT_BK", 32);
+    // 64-key tiles (one workgroup per CU) for a handful of work items - one utterance, or a few long ones: half the
+    // trips of the serial chain (us per launch, 32 / 64 keys: 1 x 120 phones 8.9 / 8.2, 1 x 512 22.7 / 20.2, 4 x 512
+    // 23.2 / 20.8; batches: 32 x ~120 11.2 / 11.5, 128 x ~120 25.2 / 30.2)
+    static const int bk_env = FS2_ENV_INT("FS2_ATTN_SPLIT_BK", 0);
+    const int bk = bk_env ? bk_env : ((long)B * H * ((max_len + 63) / 64) <= 128 ? 64 : 32);
     static const int xcd_on = FS2_ENV_INT("FS2_ATTN_XCD", 1);
     AttnArgs aa = a;
     const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 63) / 64, H, B, xcd_on != 0);

@@ -634,7 +634,9 @@ def _split_values(t):
 
 
 @pytest.mark.parametrize("h,dk,lens", [(2, 128, [120, 64, 33, 1, 200]), (2, 64, [130, 64, 257, 1, 90, 31, 7, 300, 12, 45]),
-                                       (2, 128, [512, 77]), (4, 64, [16, 17, 63, 65])])
+                                       (2, 128, [512, 77]), (4, 64, [16, 17, 63, 65]),
+                                       # more than 128 work items: 32-key tiles (fewer: 64-key tiles, one workgroup per CU)
+                                       (2, 128, [120, 64, 33, 1, 200, 90, 150] * 6), (2, 64, [130, 64, 257, 1, 90, 31, 7, 300, 12, 45] * 4)])
 def test_attention_on_split_fp16_operands_is_fp32_grade(h, dk, lens):
     """fs2_attention dtype 3 (FS2_F16X3_QKV): q | k | v in split-fp16 storage, both products as three fp16 MFMAs
     (csrc/attention.hip attention_split_kernel), against the fp64 attention of the operand values hi + lo

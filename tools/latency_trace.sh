@@ -1,8 +1,8 @@
-# kernel-by-kernel trace of one batch-1 forward (BASELINE config 1): usage (on the GPU box)  bash tools/latency_trace.sh OUT.txt
+# kernel-by-kernel trace of one batch-1 forward: usage (on the GPU box)  bash tools/latency_trace.sh OUT.txt [n_phones]   (120: BASELINE config 1)
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/lat_trace; mkdir -p $O
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/tools/latency_profile.py > $O/log.txt 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/prof -- python3 $R/tools/latency_profile.py f16x3 ${2:-120} > $O/log.txt 2>&1
 cd $R
 python3 - $O > ${1:-$O/seq.txt} <<'P'
 import csv, glob, sys
