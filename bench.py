@@ -57,7 +57,7 @@ import torch                                                         # noqa: E40
 from fastspeech2_amd import synth                                   # noqa: E402
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md chip table (dense)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x3": 2500.0}   # MI355X_MICROARCH.md chip table (dense; f16x3: the fp16 pipe, 3 MFMAs per product)
 PEAK_HBM_GBS = 8000.0                            # HBM3E spec (6.3 TB/s measured achievable, same guide)
 COPY_RATE_GBS = 6290.0                           # measured float4 copy on MI355X (same guide): what a streaming kernel can reach
 HOP_SECONDS = 256.0 / 22050.0                    # assumed hop (reference defines none)
@@ -69,7 +69,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "f16x3"],
+                    help="frame-level half; f16x3 = fp32-grade results on error-compensated fp16 operand pairs (3 MFMAs per product)")
     ap.add_argument("--encoder-dtype", default="f16x3", choices=["bf16", "fp32", "f16x3"],
                     help="phone-level half (encoder + duration predictor). f16x3 (default): error-compensated fp16 GEMM "
                          "operands, durations bit-exact vs the fp32 engine / reference goldens; bf16: ~1 %% of the "
@@ -284,7 +285,8 @@ def main():
         main_tags = [t for t in ("ffn1:" + args.dtype, "ffn2:" + args.dtype) if t in agg]
         roofline = entry(main_tags, "fs2::conv_gemm_kernel<%s, ..., KT=9> (the k=9 FFN convs of the frame-level half%s; own "
                          "kernel symbol; timed one forward at a time, i.e. without the cross-batch overlap of the "
-                         "throughput loop)" % (args.dtype, "" if args.encoder_dtype != args.dtype else " and the phone-level half"))
+                         "throughput loop)" % (args.dtype, "" if args.encoder_dtype != args.dtype else " and the phone-level half"),
+                         3 if args.dtype == "f16x3" else 1)
         traffic = None     # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
         # (a PMC pass cannot run inside this process: the figure is the newest committed measurement of the same kernel
         #  on the same launches - tools/collect_round.sh: FETCH_SIZE / WRITE_SIZE passes over tools/ffn_conv_replay.py)

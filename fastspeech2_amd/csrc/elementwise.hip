@@ -1003,8 +1003,13 @@ extern "C" int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phon
     FS2_CHECK_ARG(hs && cum && cu_phone && cu_frames && frame_seg && frame_pos && lr_index && (out_f32 || out_t),
                   "fs2_lr_gather: null pointer");
     FS2_CHECK_ARG(B > 0 && d > 0 && d % 4 == 0, "fs2_lr_gather: bad dims");
+    FS2_CHECK_ARG(dtype >= 0 && dtype <= 2 && (dtype != 2 || !out_t || (d % 32 == 0 && ((uintptr_t)out_t & 127) == 0)),
+                  "fs2_lr_gather: dtype=%d (split-fp16 copy: d a multiple of 32, out_t 128-byte aligned)", dtype);
     if (Mf <= 0) return FS2_OK;
-    if (dtype == 1)
+    if (dtype == 2)
+        hipLaunchKernelGGL(lr_gather_kernel<f16pair_t>, dim3(blocks_for(Mf, 4 * LRG_FRAMES)), dim3(256), 0, stream, hs, cum, cu_phone,
+                           cu_frames, B, out_f32, (f16pair_t*)out_t, (int2*)frame_seg, frame_pos, lr_index, Mf, d);
+    else if (dtype == 1)
         hipLaunchKernelGGL(lr_gather_kernel<bf16_t>, dim3(blocks_for(Mf, 4 * LRG_FRAMES)), dim3(256), 0, stream, hs, cum, cu_phone,
                            cu_frames, B, out_f32, (bf16_t*)out_t, (int2*)frame_seg, frame_pos, lr_index, Mf, d);
     else
@@ -1023,8 +1028,14 @@ static int variance_add_entry(const float* hs, const float* pitch, const float* 
                   "fs2_variance_add_posenc: null pointer");
     FS2_CHECK_ARG(d > 0 && d % 4 == 0 && pdim >= 1 && edim >= 1, "fs2_variance_add_posenc: bad dims");
     if (M <= 0) return FS2_OK;
+    FS2_CHECK_ARG(dtype >= 0 && dtype <= 2 && (dtype != 2 || !out_t || (d % 32 == 0 && ((uintptr_t)out_t & 127) == 0)),
+                  "fs2_variance_add_posenc: dtype=%d (split-fp16 copy: d a multiple of 32, out_t 128-byte aligned)", dtype);
     const long long n = (long long)((M + VAP_ROWS - 1) / VAP_ROWS) * (d / 4);
-    if (dtype == 1)
+    if (dtype == 2)
+        hipLaunchKernelGGL(variance_add_posenc_kernel<f16pair_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
+                           energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, alpha_dev, hs_va, out_f32,
+                           (f16pair_t*)out_t, M, d, pdim, edim);
+    else if (dtype == 1)
         hipLaunchKernelGGL(variance_add_posenc_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, stream, hs, pitch,
                            energy, Wp, bp, We, be, pscale, escale, pe, pos, xscale, alpha, alpha_dev, hs_va, out_f32,
                            (bf16_t*)out_t, M, d, pdim, edim);

@@ -167,8 +167,10 @@ class Engine:
         self.dev = torch.device(device) if device is not None else hip.require_gpu()
         hip.load()
         self.cfg = cfg
-        if dtype not in ("fp32", "bf16"):
-            raise ValueError("dtype must be 'fp32' or 'bf16' (f16x3 is a phone-level option: encoder_dtype)")
+        if dtype not in ("fp32", "bf16", "f16x3"):
+            raise ValueError("dtype must be 'fp32', 'bf16' or 'f16x3'")
+        if dtype == "f16x3" and (cfg["adim"] % 32 != 0 or encoder_dtype not in (None, "fp32", "f16x3")):
+            raise NotImplementedError("dtype='f16x3' needs adim in multiples of 32 and an fp32 / f16x3 phone-level half")
         self.dec_code = hip.DTYPE_CODE[dtype]
         enc_gemm = hip.DTYPE_CODE[encoder_dtype or dtype]
         self.enc_code = enc_gemm          # type of the phone-level GEMM inputs ("T copies"); F16X3 = split-fp16 storage
@@ -229,7 +231,9 @@ class Engine:
         self.odim = self.b_out.shape[0] // self.r
         # repaired PostNet: eval-mode BatchNorm folded into the conv (scale on W, shift as bias)
         self.postnet = []
-        tdt = hip.TORCH_DTYPE[self.dec_code]
+        # f16x3: the PostNet stays on exact-fp32 MFMA (its first conv reads odim = 80 channels, not whole 32-channel runs,
+        # and the f16x3 GEMM has no tanh epilogue)
+        self.post_code = F32 if self.dec_code == hip.F16X3 else self.dec_code
         for j in range(cfg["postnet_layers"]):
             w = g("postnet.postnet.%d.0.weight" % j)                        # (Cout, Cin, k), bias=False
             bias = torch.zeros(w.shape[0], device=dev)
@@ -238,7 +242,7 @@ class Engine:
                 scale = g(p + "weight") / torch.sqrt(g(p + "running_var") + 1e-5)
                 bias = g(p + "bias") - g(p + "running_mean") * scale
                 w = w * scale.view(-1, 1, 1)
-            self.postnet.append(dict(w=pack_gemm_weight(w, self.dec_code), b=bias.contiguous(), taps=w.shape[-1],
+            self.postnet.append(dict(w=pack_gemm_weight(w, self.post_code), b=bias.contiguous(), taps=w.shape[-1],
                                      cout=w.shape[0], cin=w.shape[1]))
         self.reg_w = False             # True: fs2_gemm_regw for the q | k | v projection of big batches (21.3 vs 22.8 us alone,
                                        # no difference in the overlapped step: bench.py --engine-set reg_w=1)
@@ -597,7 +601,7 @@ class Engine:
         seg_f = self._empty((max(Mf, 1), 2), dtype=torch.int32)
         pos_f = self._empty((max(Mf, 1),), dtype=torch.int32)
         lr_index = self._empty((max(Mf, 1),), dtype=torch.int32)
-        with self._timed("lr_gather", "byte", Mp * (4.0 * d + 12) + Mf * (4.0 * d + (2.0 * d if dc != F32 else 0.0) + 16)):
+        with self._timed("lr_gather", "byte", Mp * (4.0 * d + 12) + Mf * (4.0 * d + (0.0 if dc == F32 else (2.0 if dc == hip.BF16 else 4.0) * d) + 16)):
             call("fs2_lr_gather", ptr(hs32), ptr(cum), ptr(cu_phone), ptr(cu_frames), B, ptr(hs_lr32), ptr(hs_lrt),
                  ptr(seg_f), ptr(pos_f), ptr(lr_index), Mf, d, dc, stream())
         if dc == F32:
@@ -662,12 +666,13 @@ class Engine:
         mel = before
         if self.postnet:      # after = before + postnet(before)   (network/fastspeech2.py:222-225)
             cur = before
-            if dc != F32:
-                cur = self._empty((Mo, self.odim), dc)
-                call("fs2_cast", ptr(before), ptr(cur), Mo * self.odim, dc, stream())
+            pc_ = self.post_code
+            if pc_ != F32:
+                cur = self._empty((Mo, self.odim), pc_)
+                call("fs2_cast", ptr(before), ptr(cur), Mo * self.odim, pc_, stream())
             for j, L in enumerate(self.postnet):
                 last = j == len(self.postnet) - 1
-                cur = self._gemm(cur, L["w"], L["b"], Mo, L["cout"], L["cin"], L["taps"], dc,
+                cur = self._gemm(cur, L["w"], L["b"], Mo, L["cout"], L["cin"], L["taps"], pc_,
                                  seg=seg_o if L["taps"] > 1 else None, res=before if last else None,
                                  relu=0 if last else 2, out_f32=last)
             mel = cur

@@ -265,9 +265,11 @@ class FeedForwardTransformer(nn.Module):
 
     # ------------------------------------------------------------------ engine plumbing
     def set_precision(self, dtype: str = "fp32", encoder_dtype: Optional[str] = None):
-        """'fp32' (parity mode) or 'bf16' (bf16 MFMA operands).  encoder_dtype='fp32' keeps the
-        phone-level half — which fixes the integer durations — in fp32 under dtype='bf16'."""
-        assert dtype in ("fp32", "bf16") and encoder_dtype in (None, "fp32", "bf16", "f16x3")
+        """'fp32' (parity mode, exact-fp32 MFMA), 'bf16' (bf16 MFMA operands) or 'f16x3' (every GEMM and the attention
+        on error-compensated fp16 operand pairs: fp32-grade results - mel within the fp32 bar - at a fraction of the
+        exact-fp32 time).  encoder_dtype='fp32' / 'f16x3' keeps the phone-level half - which fixes the integer
+        durations - at that precision under dtype='bf16'."""
+        assert dtype in ("fp32", "bf16", "f16x3") and encoder_dtype in (None, "fp32", "bf16", "f16x3")
         self._precision = (dtype, encoder_dtype)
         self._engine = None
         return self

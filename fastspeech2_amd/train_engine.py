@@ -98,6 +98,8 @@ class TrainEngine:
         self.model = model
         cfg = model.cfg
         self.cfg = cfg
+        if dtype not in ("fp32", "bf16"):
+            raise NotImplementedError("the training step runs in 'fp32' or 'bf16' (set_precision(%r) is an inference mode)" % dtype)
         self.code = hip.DTYPE_CODE[dtype]
         self.tdt = hip.TORCH_DTYPE[self.code]
         self.epv = 4 if self.code == F32 else 8

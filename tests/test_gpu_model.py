@@ -28,10 +28,18 @@ def build_model(meta, precision="fp32", encoder_dtype=None):
     return model
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("name", helpers.INFER_CASES)
-def test_fp32_matches_reference_golden(name):
+def test_fp32_matches_reference_golden(name, precision):
+    """Both fp32-grade modes against the reference's golden vectors at the north_star's fp32 bars: 'fp32' (exact-fp32
+    MFMA) and 'f16x3' (every GEMM and the attention on error-compensated fp16 operand pairs, frame level included)."""
     z, meta = helpers.load_golden(name)
-    model = build_model(meta)
+    try:
+        model = build_model(meta, precision)
+        model.engine()
+    except NotImplementedError as e:          # f16x3: channel counts that are not whole 32-element runs
+        assert precision == "f16x3"
+        pytest.skip(str(e))
     dc = meta["duration_control"]
     xs = [torch.from_numpy(z["ids_%d" % i]) for i in range(meta["n"])]
     # per utterance through the reference API
@@ -243,6 +251,35 @@ def test_f16x3_encoder_durations_equal_the_fp32_engine_on_the_bench_batch():
         assert np.array_equal(durs["f16x3"][cu[b]:cu[b + 1]], o["durations"].numpy())
         worst = max(worst, np.abs(logd[cu[b]:cu[b + 1]] - o["log_durations"].numpy()).max())
     assert worst <= 5e-6, worst          # fp32 summation-order noise level (measured 1e-6; bf16 encoder: 4e-3)
+
+
+def test_f16x3_everywhere_is_fp32_grade_on_the_bench_batch():
+    """set_precision("f16x3"): frame-level half on error-compensated fp16 operands as well.  BASELINE config 2 batch against
+    the exact-fp32 engine: every duration equal, mel / pitch / energy at fp32 summation-noise level (the north_star's fp32
+    bar is 1e-3 on mel; a bf16 frame-level half measures 1e-2), and against the CPU oracle on four utterances."""
+    from fastspeech2_amd import synth
+    kw = dict(synth.BASELINE_OVERRIDES)
+    sd = synth.bench_state_dict()
+    xs = [torch.from_numpy(x) for x in synth.synth_utterances(32, 0)]
+    res = {}
+    for prec in ("fp32", "f16x3"):
+        model = FeedForwardTransformer(80, 80, use_scaled_pos_enc=True, **kw)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        model.eval().cuda().set_precision(prec)
+        pk = model.infer_batch(xs)["packed"]
+        res[prec] = {k: pk[k].float().cpu().numpy() for k in ("durations", "mel", "pitch", "energy")}
+        res[prec]["olens"] = list(pk["olens"])
+    assert np.array_equal(res["fp32"]["durations"], res["f16x3"]["durations"])
+    assert res["fp32"]["olens"] == res["f16x3"]["olens"]
+    worst = {k: float(np.abs(res["fp32"][k] - res["f16x3"][k]).max()) for k in ("mel", "pitch", "energy")}
+    print("f16x3 everywhere vs exact fp32 on the bench batch:", worst)
+    assert max(worst.values()) <= 5e-5, worst          # measured 8-9e-6
+    cfg = fs2_oracle.full_cfg(80, 80, use_scaled_pos_enc=True, **kw)
+    sd_t = {k: torch.from_numpy(v) for k, v in sd.items()}
+    cu = np.concatenate([[0], np.cumsum(res["f16x3"]["olens"])])
+    for b in (0, 13, 31):
+        o = fs2_oracle.infer_one(sd_t, cfg, xs[b])
+        assert np.abs(res["f16x3"]["mel"][cu[b]:cu[b + 1]] - o["mel"].numpy()).max() <= FP32_MEL_TOL
 
 
 @pytest.mark.parametrize("n_phones", [120, 37, 450])
