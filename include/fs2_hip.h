@@ -210,7 +210,8 @@ int fs2_cu_from_lens(const int* lens, int* cu, int n, hipStream_t stream);
 
 /* LengthRegulator expansion + pad_list (network/variance_adaptor.py:31, network/utils.py:50-56) into
  * the packed frame matrix: out[f,:] = hs[cu_phone[b] + lr_index[f], :].  Also emits the frame-level
- * row tables (seg, pos) and the index map lr_index (phone index inside the utterance). */
+ * row tables (seg, pos) and the index map lr_index (phone index inside the utterance).  out_t: the T copy (dtype 1: bf16,
+ * 2: split-fp16 storage, d % 32 == 0 and 128-byte aligned). */
 int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phone, const int* cu_frames, int B,
                   float* out_f32, void* out_t, int* frame_seg, int* frame_pos, int* lr_index, int Mf, int d,
                   int dtype, hipStream_t stream);
@@ -218,7 +219,7 @@ int fs2_lr_gather(const float* hs, const int* cum, const int* cu_phone, const in
 /* hs_va = hs + (energy_embed(e*escale) + pitch_embed(p*pscale)) for kernel-size-1 VarianceEmbedding
  * (network/variance_adaptor.py:35-51, :203-206), then the decoder positional encoding
  * out = hs_va * xscale + alpha * pe[pos] (network/encoder.py:216-219).  hs_va / out_f32 / out_t may be NULL
- * (at least one of out_f32, out_t is required). */
+ * (at least one of out_f32, out_t is required; out_t in T: dtype 1 bf16, 2 split-fp16 storage with d % 32 == 0). */
 int fs2_variance_add_posenc(const float* hs, const float* pitch, const float* energy, const float* Wp,
                             const float* bp, const float* We, const float* be, float pscale, float escale,
                             const float* pe, const int* pos, float xscale, float alpha, float* hs_va,
