@@ -20,7 +20,7 @@ def run(eng, xs, iters=20):
     fr = sum(out["olens"])
     return dt * 1e3, fr, fr / dt
 
-for dtype, enc in (("bf16", "f16x3"), ("bf16", "bf16"), ("fp32", "fp32")):
+for dtype, enc in (("bf16", "f16x3"), ("bf16", "bf16"), ("f16x3", "f16x3"), ("fp32", "fp32")):
     model, _, _ = bench.build_model(dtype, enc, torch.device("cuda", 0))
     eng = model.engine()
     dtype = dtype if enc == dtype else "%s+%s" % (dtype, enc)

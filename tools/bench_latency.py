@@ -15,7 +15,7 @@ def timeit(fn, n=200, warm=20):
 import bench
 model, _, _ = bench.build_model("fp32", None, "cuda:0")
 ids = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).integers(1, synth.BENCH_IDIM, size=120))
-for prec in (("bf16", "f16x3"), ("bf16", "bf16"), ("fp32", None)):
+for prec in (("bf16", "f16x3"), ("bf16", "bf16"), ("f16x3", None), ("fp32", None)):
     model.set_precision(prec[0], prec[1])
     for kv in sys.argv[1:]:
         k, v = kv.split("=")

@@ -19,6 +19,8 @@ cd $R
 python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/${T}_ffn_conv_traffic.json 24 Li9E > $O/pmc_traffic.log 2>&1; echo traffic ok
 timeout -k 10 300 python3 bench_train.py --steps 30 --warmup 5 > $O/${T}_train_dropout.json 2> $O/train.err; echo train ok
 timeout -k 10 400 python3 tools/bench_configs.py > $O/${T}_configs.txt 2>&1; echo configs ok
+timeout -k 10 300 python3 tools/bench_latency.py > $O/${T}_batch1_latency.txt 2>&1; echo latency ok
+timeout -k 10 300 python3 bench.py --dtype f16x3 --no-cpu-baseline > $O/${T}_bench_f16x3.json 2>> $O/${T}_bench.err; echo f16x3 ok
 rm -f $O/prof_*/*/*kernel_trace.csv $O/prof_*/*/*agent_info.csv; rm -rf $O/pmc_fetch $O/pmc_write
 cp $O/prof_serial/*/*kernel_stats.csv $O/${T}_bench_serial_kernel_stats.csv
 cp $O/prof_overlap/*/*kernel_stats.csv $O/${T}_bench_overlap_kernel_stats.csv
