@@ -142,6 +142,13 @@ class TrainEngine:
         self._side_raw = self.wgrad_stream.cuda_stream if self.wgrad_stream is not None else None   # raw hipStream_t of the side stream
         self._ws_cache = {}
         self._wgrad_pending = False
+        # Weight-gradient launches wait in a queue and go to the side stream a few at a time behind ONE event: a fork
+        # (event record + wait on the other stream) costs ~24 us of host time with kernels in flight
+        # (tools/microbench/event_cost.py) and the step is bound by the host; FS2_TRAIN_WGRAD_BATCH=1: one fork per launch
+        self._wq = []
+        self.wgrad_batch = max(1, int(os.environ.get("FS2_TRAIN_WGRAD_BATCH", "4") or 4))
+        self._wgrad_sync = os.environ.get("FS2_TRAIN_WGRAD_SYNC", "0") == "1"   # debugging aid: the streams never run side by side
+        self._size_cache = {}
 
     # ------------------------------------------------------------------ set-up
     def _stack_weights(self, prefix, n_layers, concat_after):
@@ -360,7 +367,7 @@ class TrainEngine:
         of = self._empty((M, C), torch.float32) if (want_f32 or (want_t and f32) or split_t) else None
         ot = self._empty((M, C)) if (want_t and (not f32 or split_t)) else None
         nparts = 0 if parts is None else (parts.shape[0] if parts.dim() == 3 else 1)
-        ws = self._ws(hip.load().fs2_layernorm_bwd_workspace(M, C)) if w is not None else None
+        ws = self._ws(self._size("fs2_layernorm_bwd_workspace", M, C)) if w is not None else None
         call("fs2_layernorm_bwd", ptr(x), ptr(dy), ptr(parts), nparts, M * C, ptr(w), ptr(dres), int(relu_gate), ptr(of),
              ptr(ot), ptr(dw), ptr(db), ptr(ws), M, C, LN_EPS, 0, self.code, self.seed, ind[0], ind[1], td[0], td[1],
              stream())
@@ -380,7 +387,7 @@ class TrainEngine:
         """weight gradient (+ bias gradient = column sums of dy when dbias is given)"""
         ks = self._wgrad_split(M, N, Cin, taps)
         if self.wgrad_stream is None or self.profile is not None:
-            ws = self._ws(hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks))
+            ws = self._ws(self._size("fs2_conv_wgrad_workspace", N, Cin, taps, ks))
             t0 = self._tic(tag)
             call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(ws), ptr(seg) if taps > 1 else None, M, N,
                  Cin, taps, N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0, stream())
@@ -388,23 +395,43 @@ class TrainEngine:
             return
         # weight gradients are leaves of the backward: they run on a side stream, beside the input-gradient
         # chain on the main stream (ordered after the kernel that produced dy; joined before the buckets are used)
+        self._wq.append((dy, x, grad, seg if taps > 1 else None, M, N, Cin, taps, N if ldy is None else ldy,
+                         Cin if ldx is None else ldx, dbias, ks))
+        if len(self._wq) >= self.wgrad_batch or self._wgrad_sync:
+            self._flush_wgrad()
+        if self._wgrad_sync:
+            self._join_wgrad()
+
+    def _size(self, name, *args):
+        """workspace-size query of the library, memoised (pure function of the shape)"""
+        key = (name,) + args
+        v = self._size_cache.get(key)
+        if v is None:
+            v = self._size_cache[key] = int(getattr(hip.load(), name)(*args))
+        return v
+
+    def _flush_wgrad(self):
+        """queued weight-gradient launches -> side stream, ordered after everything enqueued on the main stream so far"""
+        q = self._wq
+        if not q:
+            return
+        self._wq = []
         side = self.wgrad_stream
         ev = torch.cuda.Event()
         ev.record()
         side.wait_event(ev)
-        nbytes = hip.load().fs2_conv_wgrad_workspace(N, Cin, taps, ks)
-        buf = self._ws_cache.get(self._side_raw)
-        if buf is None or buf.numel() * 4 < nbytes:
-            with torch.cuda.stream(side):          # (the caching allocator ties the block to the side stream)
-                buf = self._ws(nbytes, self._side_raw)
-        call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(buf), ptr(seg) if taps > 1 else None, M, N,
-             Cin, taps, N if ldy is None else ldy, Cin if ldx is None else ldx, self.code, ks, 1.0, 0,
-             hip.c_void_p(self._side_raw))
-        dy.record_stream(side)
-        x.record_stream(side)
+        raw = hip.c_void_p(self._side_raw)
+        for dy, x, grad, seg, M, N, Cin, taps, ldy, ldx, dbias, ks in q:
+            nbytes = self._size("fs2_conv_wgrad_workspace", N, Cin, taps, ks)
+            buf = self._ws_cache.get(self._side_raw)
+            if buf is None or buf.numel() * 4 < nbytes:
+                with torch.cuda.stream(side):          # (the caching allocator ties the block to the side stream)
+                    buf = self._ws(nbytes, self._side_raw)
+            call("fs2_conv_wgrad", ptr(dy), ptr(x), ptr(grad), ptr(dbias), ptr(buf), ptr(seg), M, N, Cin, taps, ldy, ldx,
+                 self.code, ks, 1.0, 0, raw)
+            dy.record_stream(side)
+            x.record_stream(side)
         self._wgrad_pending = True
-        if os.environ.get("FS2_TRAIN_WGRAD_SYNC", "0") == "1":      # debugging aid: the streams never run side by side
-            self._join_wgrad()
 
     def producer_streams(self):
         """streams whose enqueued work writes the gradient buffer (a bucket consumer must order itself after both)"""
@@ -414,12 +441,14 @@ class TrainEngine:
         return out
 
     def _join_wgrad(self):
+        if self.wgrad_stream is not None:
+            self._flush_wgrad()
         if self.wgrad_stream is not None and self._wgrad_pending:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._wgrad_pending = False
 
     def _colsum(self, G, out, M, C, ldg=None, g_is_t=True, S=None, R=1, scale=1.0, pe=None, pos=None):
-        ws = self._ws(hip.load().fs2_colreduce_workspace(M, C, R))
+        ws = self._ws(self._size("fs2_colreduce_workspace", M, C, R))
         gd = 1 if (g_is_t and self.code == BF16) else 0
         call("fs2_colreduce", ptr(G), gd, C if ldg is None else ldg, ptr(S), 0 if S is None else S.shape[1], R, ptr(pe),
              ptr(pos), ptr(out), ptr(ws), M, C, float(scale), 0, stream())
@@ -549,6 +578,7 @@ class TrainEngine:
                                    t_drop=(self._sites(side, n - 1)["res_f"], r_res))
             dparts = None
         if self.grad_ready is not None:
+            self._flush_wgrad()
             self.grad_ready(first_ready)
         for li in range(n - 1, -1, -1):
             L, r = layers[li], saved["layers"][li]
@@ -613,6 +643,7 @@ class TrainEngine:
             else:                # a = x: d x = dy + da, folded into the next LayerNorm backward
                 dparts = da
             if self.grad_ready is not None:
+                self._flush_wgrad()
                 self.grad_ready(self._bucket_of[p])
         return dy, dparts
 
