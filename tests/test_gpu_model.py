@@ -103,17 +103,18 @@ def test_bf16_with_fp32_encoder_keeps_durations_exact():
         assert np.abs(out["mel"][i, :T].cpu().numpy() - z["mel_%d" % i]).max() <= BF16_MEL_TOL
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
 @pytest.mark.parametrize("name", helpers.LONG_CASES)
-def test_long_utterance_config4(name):
+def test_long_utterance_config4(name, precision):
     """BASELINE config 4: 512 phones -> 4165 frames at BASELINE dims against the reference's own output (sampled mel
-    rows + row / column sums of every frame), alone and as one row of a 4-utterance batch; fp32 to the north_star
-    bars, bf16 (teacher-forced durations) to the stated bf16 tolerance."""
+    rows + row / column sums of every frame), alone and as one row of a 4-utterance batch; both fp32-grade modes (exact
+    fp32 MFMA, f16x3) to the north_star's fp32 bars, bf16 (teacher-forced durations) to the stated bf16 tolerance."""
     z, meta = helpers.load_golden(name)
     ids = torch.from_numpy(z["ids_0"])
     T = int(z["frames_0"])
     rows = helpers.long_mel_rows(T)
     idx, _ = fs2_oracle.length_regulate_index(z["dur_pred_0"])
-    model = build_model(meta)
+    model = build_model(meta, precision)
     # a short utterance first: the cached positional table (1024 rows) has to re-grow for 4165 frames
     assert model.inference(ids[:9].cuda(), None).shape[1] == meta["cfg"]["odim"]
     others = [ids[:300], ids[100:], torch.flip(ids, [0])]
@@ -131,6 +132,8 @@ def test_long_utterance_config4(name):
         assert np.abs(pk["enc_out"].cpu().numpy()[:512][::8] - z["enc_out_0"]).max() <= 1e-3
         assert np.abs(pk["pitch"].cpu().numpy()[:T] - z["pitch_0"]).max() <= 1e-3
         assert np.abs(pk["energy"].cpu().numpy()[:T] - z["energy_0"]).max() <= 1e-3
+    if precision != "fp32":
+        return
     # bf16, durations teacher-forced from the reference
     eng = build_model(meta, "bf16").engine()
     ds = torch.from_numpy(z["dur_after_lr_0"].astype(np.int32)).cuda()

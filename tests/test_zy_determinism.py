@@ -22,7 +22,7 @@ def _bench_model():
     return model.eval().cuda()
 
 
-@pytest.mark.parametrize("precision,encoder", [("bf16", "f16x3"), ("bf16", None), ("fp32", None)])
+@pytest.mark.parametrize("precision,encoder", [("bf16", "f16x3"), ("bf16", None), ("f16x3", None), ("fp32", None)])
 def test_inference_repeats_are_bit_identical(precision, encoder):
     """BASELINE config 2 (32 utterances, ~25 k frames) through the throughput loop (side-stream phone-level halves,
     three frame-level streams): 4 batches x 3 repeats, every output tensor equal bit for bit."""
