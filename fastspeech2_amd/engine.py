@@ -231,9 +231,9 @@ class Engine:
         self.odim = self.b_out.shape[0] // self.r
         # repaired PostNet: eval-mode BatchNorm folded into the conv (scale on W, shift as bias)
         self.postnet = []
-        # f16x3: the PostNet stays on exact-fp32 MFMA (its first conv reads odim = 80 channels, not whole 32-channel runs,
-        # and the f16x3 GEMM has no tanh epilogue)
-        self.post_code = F32 if self.dec_code == hip.F16X3 else self.dec_code
+        # f16x3: a PostNet conv whose input channels are not whole 32-channel runs (the first one reads odim = 80) runs on
+        # exact-fp32 MFMA, its output is converted to split-fp16 storage for the next conv
+        self.post_code = self.dec_code
         for j in range(cfg["postnet_layers"]):
             w = g("postnet.postnet.%d.0.weight" % j)                        # (Cout, Cin, k), bias=False
             bias = torch.zeros(w.shape[0], device=dev)
@@ -242,8 +242,9 @@ class Engine:
                 scale = g(p + "weight") / torch.sqrt(g(p + "running_var") + 1e-5)
                 bias = g(p + "bias") - g(p + "running_mean") * scale
                 w = w * scale.view(-1, 1, 1)
-            self.postnet.append(dict(w=pack_gemm_weight(w, self.post_code), b=bias.contiguous(), taps=w.shape[-1],
-                                     cout=w.shape[0], cin=w.shape[1]))
+            lc = F32 if (self.post_code == hip.F16X3 and w.shape[1] % 32 != 0) else self.post_code
+            self.postnet.append(dict(w=pack_gemm_weight(w, lc), b=bias.contiguous(), taps=w.shape[-1],
+                                     cout=w.shape[0], cin=w.shape[1], code=lc))
         self.reg_w = False             # True: fs2_gemm_regw for the q | k | v projection of big batches (21.3 vs 22.8 us alone,
                                        # no difference in the overlapped step: bench.py --engine-set reg_w=1)
         self.fused_proj_ln = True      # post-LN blocks at d = 256, bf16: output projection + residual + norm1 as one kernel (csrc/proj_ln.hip)
@@ -347,7 +348,7 @@ class Engine:
                                int(out_f32))):
                 call("fs2_gemm_regw", ptr(x), ptr(w), ptr(bias), ptr(out), M, N, Cin, Cin, N, int(out_f32), code, stream())
             elif wscale is not None:          # split-fp16 operands (pack_gemm_weight / T copies of code F16X3)
-                assert code == hip.F16X3 and int(relu) in (0, 1)
+                assert code == hip.F16X3 and int(relu) in (0, 1, 2)
                 call("fs2_conv_gemm_f16x3", ptr(x), ptr(w), wscale, ptr(bias), ptr(res), ptr(out), ptr(seg), M, N, Cin,
                      taps, Cin, N, N, int(relu), int(out_f32), ksplit, M * N, stream())
             else:
@@ -666,15 +667,19 @@ class Engine:
         mel = before
         if self.postnet:      # after = before + postnet(before)   (network/fastspeech2.py:222-225)
             cur = before
-            pc_ = self.post_code
-            if pc_ != F32:
-                cur = self._empty((Mo, self.odim), pc_)
-                call("fs2_cast", ptr(before), ptr(cur), Mo * self.odim, pc_, stream())
+            cur_code = F32                      # storage of `cur`
             for j, L in enumerate(self.postnet):
                 last = j == len(self.postnet) - 1
-                cur = self._gemm(cur, L["w"], L["b"], Mo, L["cout"], L["cin"], L["taps"], pc_,
+                lc = L["code"]
+                if lc != cur_code:              # fp32 -> the layer's operand storage (bf16 / split-fp16)
+                    assert cur_code == F32
+                    nxt = self._empty((Mo, L["cin"]), lc)
+                    call("fs2_cast", ptr(cur), ptr(nxt), Mo * L["cin"], lc, stream())
+                    cur = nxt
+                cur = self._gemm(cur, L["w"], L["b"], Mo, L["cout"], L["cin"], L["taps"], lc,
                                  seg=seg_o if L["taps"] > 1 else None, res=before if last else None,
                                  relu=0 if last else 2, out_f32=last)
+                cur_code = F32 if (last or lc == F32) else lc
             mel = cur
         # olens / cu_frames count decoder frames (pitch, energy, attention); mel_lens / cu_mel the mel rows (= r times those)
         out = dict(mel=mel, mel_before=before, olens=olens, cu_frames=cu_frames, mel_lens=mel_lens, cu_mel=cu_mel,

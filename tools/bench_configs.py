@@ -36,7 +36,7 @@ for dtype, enc in (("bf16", "f16x3"), ("bf16", "bf16"), ("f16x3", "f16x3"), ("fp
 # the shipped param/fastspeech.yaml (6+6 linear-FFN blocks, d=384, 4 heads, PostNet 5x256), random init
 from fastspeech2_amd.network.fastspeech2 import FeedForwardTransformer
 from fastspeech2_amd.param.load_param import load_config
-for dtype, enc in (("bf16", "f16x3"), ("bf16", None), ("fp32", None)):
+for dtype, enc in (("bf16", "f16x3"), ("bf16", None), ("f16x3", None), ("fp32", None)):
     cfg = load_config()
     sd = synth.synth_state_dict(80, 80, 1234, dur_bias=float(np.log(7.67)), dur_w_scale=0.2, **cfg)
     model = FeedForwardTransformer(80, 80, **cfg)
