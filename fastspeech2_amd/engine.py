@@ -99,18 +99,41 @@ class _Stack:
     """Packed weights of one FFT stack (encoder or decoder).  code: storage type of the activations (F32 / BF16);
     gemm_code: operand form of the GEMM weights (the same, or F16X3 over fp32 activations)."""
 
-    def __init__(self, sd, prefix, n_layers, pre_ln, concat_after, ff_type, dev, code, gemm_code=None):
+    def __init__(self, sd, prefix, n_layers, pre_ln, concat_after, ff_type, dev, code, gemm_code=None, n_heads=1):
         gc = code if gemm_code is None else gemm_code
         self.pre_ln, self.concat_after, self.code = pre_ln, concat_after, code
         f32 = lambda k: sd[prefix + k].detach().to(dev, torch.float32).contiguous()
         self.layers = []
+        self.dk = self.da = None            # head dim / q (k, v, context) width the attention runs on; set below
         for i in range(n_layers):
             p = "encoders.%d." % i
             L = {}
             wq, wk, wv = (f32(p + "self_atten.linear_%s.weight" % n) for n in "qkv")
+            bq, bk, bv = (f32(p + "self_atten.linear_%s.bias" % n) for n in "qkv")
+            wo = f32(p + "self_atten.linear_out.weight")
+            d = wq.shape[0]
+            dk = d // n_heads
+            dkp = dk
+            if gc == hip.F16X3 and dk not in (64, 128) and dk < 128:
+                # f16x3 stacks: heads padded with zero channels to 64 / 128 (the head dims of the split-fp16 attention
+                # kernel; the shipped yaml has 96): zero q / k channels add nothing to q . k, zero v channels give zero
+                # context channels that meet zero columns of linear_out.  The kernel scales by 1 / sqrt(padded dk), so
+                # linear_q carries sqrt(padded dk / dk) (network/encoder.py:73-84: scores = q . k / sqrt(d_k)).
+                dkp = 64 if dk < 64 else 128
+                fix = math.sqrt(dkp / dk)
+
+                def pad_rows(w, scale=1.0):      # (h * dk, ...) -> (h * dkp, ...)
+                    w = w.view(n_heads, dk, *w.shape[1:]) * scale
+                    out = torch.zeros((n_heads, dkp) + tuple(w.shape[2:]), device=w.device, dtype=w.dtype)
+                    out[:, :dk] = w
+                    return out.view(n_heads * dkp, *w.shape[2:]).contiguous()
+                wq, bq = pad_rows(wq, fix), pad_rows(bq, fix)
+                wk, bk, wv, bv = pad_rows(wk), pad_rows(bk), pad_rows(wv), pad_rows(bv)
+                wo = pad_rows(wo.t().contiguous()).t().contiguous()      # columns (context channels) padded
+            self.dk, self.da = dkp, n_heads * dkp
             L["wqkv"] = pack_gemm_weight(torch.cat([wq, wk, wv], 0), gc)
-            L["bqkv"] = torch.cat([f32(p + "self_atten.linear_%s.bias" % n) for n in "qkv"], 0).contiguous()
-            L["wo"] = pack_gemm_weight(f32(p + "self_atten.linear_out.weight"), gc)
+            L["bqkv"] = torch.cat([bq, bk, bv], 0).contiguous()
+            L["wo"] = pack_gemm_weight(wo, gc)
             L["bo"] = f32(p + "self_atten.linear_out.bias")
             w1, w2 = f32(p + "feed_forward.w1.weight"), f32(p + "feed_forward.w2.weight")
             L["taps"] = w1.shape[-1] if ff_type == "conv1d" else 1
@@ -193,9 +216,9 @@ class Engine:
         self.scaled = cfg["use_scaled_pos_enc"]
         ff = cfg["positionwise_layer_type"]
         self.enc = _Stack(sd, "encoder.", cfg["elayers"], cfg["encoder_normalized_before"],
-                          cfg["encoder_concat_after"], ff, dev, self.enc_code, enc_gemm)
+                          cfg["encoder_concat_after"], ff, dev, self.enc_code, enc_gemm, n_heads=self.h)
         self.dec = _Stack(sd, "decoder.", cfg["dlayers"], cfg["decoder_normalized_before"],
-                          cfg["decoder_concat_after"], ff, dev, self.dec_code)
+                          cfg["decoder_concat_after"], ff, dev, self.dec_code, n_heads=self.h)
         g = lambda k: sd[k].detach().to(dev, torch.float32).contiguous()
         self.emb = g("encoder.embed.0.weight")
         self.idim = self.emb.shape[0]
@@ -394,18 +417,19 @@ class Engine:
             # f16x3: q | k | v leave the projection in split-fp16 storage and the attention products run on the fp16 matrix
             # pipe too (csrc/attention.hip attention_split_kernel); fp32 q | k | v + exact-fp32 MFMA for head dims that
             # kernel does not serve and for the attention dumps (fs2_attention_dump reads fp32)
-            split_qkv = split and self.split_attention and self.dk in (64, 128) and attn_dump is None
-            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * d, d, 1, code, tag="qkv", out_f32=split and not split_qkv)
+            dk, da = st.dk or self.dk, st.da or d     # (an f16x3 stack may run on zero-padded heads: _Stack)
+            split_qkv = split and self.split_attention and dk in (64, 128) and attn_dump is None
+            qkv = self._gemm(a_t, L["wqkv"], L["bqkv"], M, 3 * da, d, 1, code, tag="qkv", out_f32=split and not split_qkv)
             if attn_dump is not None:
-                attn_dump.append(self._dump_attention(qkv, lens, ac))
-            ctx = self._empty((M, d), code)       # f16x3: written in split-fp16 storage by the attention kernel
+                attn_dump.append(self._dump_attention(qkv, lens, ac, dk, da))
+            ctx = self._empty((M, da), code)      # f16x3: written in split-fp16 storage by the attention kernel
             prof = self.profile is not None and lens is not None
             with self._timed("attention:" + ("fp32" if ac == F32 else "bf16") if prof else None, "flop",
                              4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
-                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, self.dk, 3 * d, d,
+                call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, dk, 3 * da, da,
                      hip.F16X3_QKV if split_qkv else code, stream())
             if st.concat_after:
-                att = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code)
+                att = self._gemm(ctx, L["wo"], L["bo"], M, d, da, 1, code)
                 pend = self._empty((2, M, d), dtype=torch.float32)
                 self._gemm(a_t, L["wc_x"], L["bc"], M, d, d, 1, code, out_f32=True, out=pend[0], res=x32)
                 self._gemm(att, L["wc_a"], None, M, d, d, 1, code, out_f32=True, out=pend[1])
@@ -418,8 +442,8 @@ class Engine:
                          ptr(L["norm1_b"]), ptr(n32), ptr(nt_), M, d, d, d, d, d, LN_EPS, code, stream())
                 x32, xt, pend = n32, nt_, None
             else:
-                pend = self._gemm(ctx, L["wo"], L["bo"], M, d, d, 1, code, out_f32=True, res=x32,
-                                  ksplit=self._ksplit(M, d, d, 1, code), tag="out_proj")
+                pend = self._gemm(ctx, L["wo"], L["bo"], M, d, da, 1, code, out_f32=True, res=x32,
+                                  ksplit=self._ksplit(M, d, da, 1, code), tag="out_proj")
             # ---- position-wise feed-forward sub-layer (:182-187)
             if st.pre_ln:
                 f_t = self._ln(None, L["norm2_w"], L["norm2_b"], M, d, code, False, True, parts=pend, sum_out=x32)[1]
@@ -441,11 +465,11 @@ class Engine:
                 x32, xt = self._ln(None, st.after_w, st.after_b, M, d, code, True, True, parts=pend)
         return x32, xt
 
-    def _dump_attention(self, qkv, lens, code):
+    def _dump_attention(self, qkv, lens, code, dk, da):
         outs, r0 = [], 0
         for L in lens:
             a = self._empty((self.h, L, L), dtype=torch.float32)
-            call("fs2_attention_dump", ptr(qkv), ptr(a), r0, L, self.h, self.dk, 3 * self.d, code, stream())
+            call("fs2_attention_dump", ptr(qkv), ptr(a), r0, L, self.h, dk, 3 * da, code, stream())
             outs.append(a)
             r0 += L
         return outs
