@@ -225,6 +225,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, const float
 
 // MODE 0: generic register staging (any Cin % 8 == 0), X/W double-buffered, synchronous
 // MODE 1: LDS-DMA, X single + W double buffer, one __syncthreads per step (3 workgroups / CU)
+// MODE 3: LDS-DMA, TWO (tap, chunk) steps per barrier: the stages of steps s + 2 and s + 3 are in flight while steps s and
+//         s + 1 compute (W ring of four stages; X ring of four images, because with k = 1 every step opens a new channel
+//         chunk).  For the 64 x 64 launches of the latency regime, whose step is bound by the barrier -> LDS read -> MFMA
+//         chain of one wave per SIMD: half the barriers, and the second step's reads overlap the first one's MFMAs.
 // Workgroup = 2 WM waves laid out WM (tokens) x 2 (channels); wave tile 16 MT x 16 NT; block tile
 // (16 MT WM) x (32 NT).  XDB: X image double-buffered (refill overlapped) or single (less LDS).
 // OCC: workgroups per CU the register allocation is tuned for.
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
     constexpr int W_BYTES = BN * CG_ROWB;
     constexpr int X_INSTR = XROWS / 8;              // 1-KiB (8-row) pieces of the X image
     constexpr int W_INSTR = BN / 8;
-    constexpr int XBUFS = XDB ? 2 : 1;
+    constexpr bool PAIR = MODE == 3;                // two steps per barrier: X ring of four images, W ring of four stages
+    constexpr int XBUFS = PAIR ? 4 : (XDB ? 2 : 1);
     typedef typename Frag<T>::type frag_t;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -487,6 +492,39 @@ __global__ __launch_bounds__(128 * WM, (OCC * 2 * WM + 3) / 4) void conv_gemm_ke
             chunk_start = chunk_lo + (int)(seed % nch);
             tap_start = (int)((seed / nch) % (unsigned)taps);
         }
+        if constexpr (PAIR) {
+            int itap = tap_start, ichunk = chunk_start, itc = 0, iord = 0, istep = 0;      // issue cursor
+            auto issue = [&]() __attribute__((always_inline)) {
+                if (itc == 0) stage_x(ichunk, iord & 3);
+                stage_w(itap, ichunk, istep & 3);
+                itap = itap + 1 == taps ? 0 : itap + 1;
+                ++istep;
+                if (++itc == taps) { itc = 0; ++iord; ichunk = ichunk + 1 == chunk_hi ? chunk_lo : ichunk + 1; }
+            };
+            if (istep < nsteps) issue();
+            if (istep < nsteps) issue();
+            vm_wait_barrier<0>();
+            int tap = tap_start, tc = 0, ord = 0;
+            for (int step = 0; step < nsteps; step += 2) {
+                // the stages this pair's successors need: their slots were last read one pair ago, behind the barrier
+                if (istep < nsteps) issue();
+                if (istep < nsteps) issue();
+                compute(tap, ord & 3, step & 3, []() {});
+                tap = tap + 1 == taps ? 0 : tap + 1;
+                if (++tc == taps) { tc = 0; ++ord; }
+                if (step + 1 < nsteps) {
+                    compute(tap, ord & 3, (step + 1) & 3, []() {});
+                    tap = tap + 1 == taps ? 0 : tap + 1;
+                    if (++tc == taps) { tc = 0; ++ord; }
+                }
+#if FS2_CONV_PIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                vm_wait_barrier<0>();
+            }
+            conv_epilogue<T, MT, NT, SPLIT>(a, bias, res, acc, m0 + wm * (16 * MT), n0 + wn * (16 * NT) + g * (4 * NT));
+            return;
+        }
         if (nsteps > 0) {
             stage_x(chunk_start, 0);
             stage_w(tap_start, chunk_start, 0);
@@ -563,7 +601,8 @@ static int conv_gemm_plan_grid(ConvGemmArgs& a, int BM, int BN, size_t elem) {
 template <typename T, int MT, int NT, int WM, int MODE, bool XDB, int OCC, int KT = 0, bool SPLIT = false>
 static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
     constexpr int BM = 16 * MT * WM, BN = 32 * NT;
-    constexpr int lds = (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
+    constexpr int lds = MODE == 3 ? 4 * (BM + CG_HALO) * CG_ROWB + 4 * BN * CG_ROWB
+                                  : (XDB ? 2 : 1) * (BM + CG_HALO) * CG_ROWB + 2 * BN * CG_ROWB;
     static unsigned long long lds_ok = 0;
     fs2_allow_lds((const void*)conv_gemm_kernel<T, MT, NT, WM, MODE, XDB, OCC, KT, SPLIT>, lds, &lds_ok);
     const int grid_x = conv_gemm_plan_grid(a, BM, BN, sizeof(T));
@@ -578,7 +617,7 @@ static int launch_conv_gemm(ConvGemmArgs a, hipStream_t stream) {
 static int dispatch_conv_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
     static const int forced = FS2_ENV_INT("FS2_SPLIT_TILE", 0);   // experiments: 22, 24, 42, 44
-    if (forced == 22) return launch_conv_gemm<float, 2, 2, 2, 1, true, 4, 0, true>(a, stream);
+    if (forced == 22) return launch_conv_gemm<float, 2, 2, 2, 3, false, 2, 0, true>(a, stream);
     if (forced == 24) return launch_conv_gemm<float, 2, 4, 2, 1, false, 3, 0, true>(a, stream);
     if (forced == 42) return launch_conv_gemm<float, 4, 2, 2, 1, false, 3, 0, true>(a, stream);
     if (forced == 44) return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
@@ -586,13 +625,15 @@ static int dispatch_conv_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
     // workgroups per CU to hide the stage latency), but the phone-level half runs beside the frame-level kernels of the
     // previous batch, and there the fewer, larger workgroups win (bench step 1.994 vs 2.02 / 2.03 ms, A/B/A/B on one box)
     // Latency regime (a few hundred tokens: one utterance): 64 x 64 tiles also for the split-K launches of up to 200
-    // large tiles, and the X image double-buffered, so that the refill at every channel-chunk change (every step of a
-    // k = 1 GEMM) travels with the W prefetch instead of waiting between two barriers of its own: batch-1 forward
-    // (BASELINE config 1) 0.876 -> 0.78 ms with the split-K schedule, -> see DESIGN 5.1 with this.
+    // large tiles, on MODE 3 (two steps per barrier, X images prefetched with the W stages, so that the refill at every
+    // channel-chunk change - every step of a k = 1 GEMM - no longer waits between two barriers of its own).  Per launch of
+    // a batch-1 forward (BASELINE config 1, rocprofv3 kernel trace, us): MODE 1 with a single X image / with two X images
+    // / MODE 3: encoder QKV 11.6 / 9.3 / 8.7, out-proj 11.9 / 9.9 / 8.8, second FFN conv 15.6 / 13.8 / 12.2; decoder first
+    // FFN conv (208 workgroups x 36 steps) 19.7 / 19.9 / 17.5, second 14.2 / 14.9 / 14.1.
     // (X and W in rings of three staged TWO steps ahead behind counted vmcnt waits, 60 KB of LDS: 5-15 % SLOWER per
     // launch here - decoder first FFN conv of one utterance 22.4 vs 19.7 us, encoder second 15.8 vs 13.6: a step of these
     // launches is bound by the barrier -> LDS read -> MFMA chain of one wave per SIMD, not by the stage's round trip)
-    if (big_blocks < 64 || (a.M <= 1024 && big_blocks < 200)) return launch_conv_gemm<float, 2, 2, 2, 1, true, 4, 0, true>(a, stream);
+    if (big_blocks < 64 || (a.M <= 1024 && big_blocks < 200)) return launch_conv_gemm<float, 2, 2, 2, 3, false, 2, 0, true>(a, stream);
     return launch_conv_gemm<float, 4, 4, 2, 1, false, 3, 0, true>(a, stream);
 }
 
@@ -603,7 +644,7 @@ static int dispatch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const long big_blocks = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.ksplit;
     const bool small = big_blocks < 200;   // would leave most of the 256 CUs idle: use 64x64 tiles
     if (!dma) return small ? launch_conv_gemm<T, 2, 2, 2, 0, true, 2>(a, stream) : launch_conv_gemm<T, 4, 4, 2, 0, true, 2>(a, stream);
-    if (small) return launch_conv_gemm<T, 2, 2, 2, 1, true, 4>(a, stream);      // X double-buffered: see dispatch_conv_gemm_split
+    if (small) return launch_conv_gemm<T, 2, 2, 2, 3, false, 2>(a, stream);     // two steps per barrier: see dispatch_conv_gemm_split
     // 128x128 (MT = 4), X image single-buffered: 50 KB of LDS -> 3 workgroups per CU.  Measured on MI355X (config-2
     // decoder FFN, bf16, random data): 128.1 us vs 154 us for the double-buffered-X / 2 WG per CU form,
     // 155 us for the 3-stage ring (MODE 2), 145-180 us for 8-wave 128x128 / 256x128 and 128x64 tiles.
