@@ -303,7 +303,8 @@ def main():
              "on error-compensated fp16 operands: 3 MFMAs per product; achieved = algorithmic FLOP/s, frac counts the 3 MFMAs)", 3),
             ("gemm_k1", ["qkv:" + d, "out_proj:" + d, "feat_out:" + d], "fs2::conv_gemm_kernel<%s, ..., KT=0>: the k=1 GEMMs of the "
              "frame-level half (QKV, output projection, feat_out)" % d, 1),
-            ("attention", ["attention:" + d], "fs2::attention_kernel<%s> (frame-level self-attention, 4 sum(T^2) d FLOP)" % d, 1),
+            ("attention", ["attention:" + d], "fs2::attention_kernel<%s> (frame-level self-attention, 4 sum(T^2) d FLOP)" % d,
+             3 if d == "f16x3" else 1),
             ("proj_add_layernorm", ["proj_ln"], "fs2::proj_ln_kernel (attention output projection + residual + norm1 of the frame-level "
              "post-LN blocks as one stream over the rows, W in registers; algorithmic bytes X + res + fp32 out + bf16 out + W)", 1),
             ("add_layernorm", ["add_layernorm"], "fs2::add_layernorm_kernel (frame level: residual + split-K partial sum + "

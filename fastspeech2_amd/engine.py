@@ -424,7 +424,7 @@ class Engine:
                 attn_dump.append(self._dump_attention(qkv, lens, ac, dk, da))
             ctx = self._empty((M, da), code)      # f16x3: written in split-fp16 storage by the attention kernel
             prof = self.profile is not None and lens is not None
-            with self._timed("attention:" + ("fp32" if ac == F32 else "bf16") if prof else None, "flop",
+            with self._timed("attention:" + ("f16x3" if split_qkv else ("fp32" if ac == F32 else "bf16")) if prof else None, "flop",
                              4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
                 call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, dk, 3 * da, da,
                      hip.F16X3_QKV if split_qkv else code, stream())
