@@ -31,6 +31,11 @@ struct AttnArgs {
     int M;
     PairOrder order;     // XCD-aware workgroup order (common.h)
     Dropout drop;        // training: dropout of the probabilities (network/encoder.py:86); site = drop.stream + head
+    // keys split over `ksplit` workgroups per (utterance, head, query block) (attention32_kernel only): each writes its
+    // unnormalised context and (m, l) to the workspace, attention_combine_kernel merges them
+    int ksplit;          // 1: no split
+    float* part_o;       // [ksplit][M][d] fp32
+    float* part_ml;      // [ksplit][H][M][2] fp32: running maximum (log2 domain), sum of exponentials
 };
 
 typedef __attribute__((address_space(3))) void at_lds_void;
@@ -358,6 +363,9 @@ __global__ __launch_bounds__(64 * NW * G, G == 1 ? 2 : 1) void attention32_kerne
 
     int b, h, qblk;
     if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
+    // key split across workgroups: the grid carries ksplit x the query blocks, block index = qblk * ksplit + split
+    const int ksplit = a.ksplit, split = qblk % ksplit;
+    qblk /= ksplit;
     const int r0 = a.cu[b];
     const int len = a.cu[b + 1] - r0;
     if (qblk * BQ >= len) return;
@@ -369,11 +377,26 @@ __global__ __launch_bounds__(64 * NW * G, G == 1 ? 2 : 1) void attention32_kerne
     const T* __restrict__ base = (const T*)a.qkv + (size_t)r0 * a.ld;
     const int qcol = h * DK, kcol = a.d + h * DK, vcol = 2 * a.d + h * DK;
 
-    // key tiles [t0, t1) of this group; every group runs `trips` iterations (barriers are workgroup-wide)
-    const int ntiles = (len + BKT - 1) / BKT;
+    // key tiles [t0, t1) of this group; every group runs `trips` iterations (barriers are workgroup-wide).  With a key
+    // split the workgroup owns tiles [s0, s1) of the utterance's.
+    const int ntiles_all = (len + BKT - 1) / BKT;
+    const int per_split = (ntiles_all + ksplit - 1) / ksplit;
+    const int s0 = split * per_split;
+    const int s1 = (s0 + per_split) < ntiles_all ? (s0 + per_split) : ntiles_all;
+    const int hq = lane >> 5, lq = lane & 31;
+    if (s0 >= s1) {       // (short utterance: this split has no keys) the merge must see "nothing": l = 0
+        const int qr = qblk * BQ + wave * 32 + lq;
+        if (grp == 0 && hq == 0 && qr < len) {
+            float* ml = a.part_ml + (((size_t)split * (a.d / DK) + h) * a.M + r0 + qr) * 2;
+            ml[0] = -INFINITY;
+            ml[1] = 0.f;
+        }
+        return;
+    }
+    const int ntiles = s1 - s0;
     const int trips = (ntiles + G - 1) / G;
-    const int t0 = grp * trips;
-    const int t1 = (t0 + trips) < ntiles ? (t0 + trips) : ntiles;
+    const int t0 = s0 + grp * trips;
+    const int t1 = (t0 + trips) < s1 ? (t0 + trips) : s1;
 
     // Slot swizzles (XOR, a rotation for the 12-slot rows of dk = 96): K rows are read 16 rows x one 16-byte slot at a
     // time (ds_read_b128 lane groups), V rows 4 rows x 64 bytes at a time (transposed reads, 32 lanes); both then
@@ -620,6 +643,26 @@ __global__ __launch_bounds__(64 * NW * G, G == 1 ? 2 : 1) void attention32_kerne
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] = o[db][r] * fa + mb[(db * 16 + r) * 64] * fb;
         }
+    }
+    if (ksplit > 1) {     // partial result of this key range: unnormalised context, running maximum, sum
+        if (qrow < len) {
+            if (hi == 0) {
+                float* ml = a.part_ml + (((size_t)split * (a.d / DK) + h) * a.M + r0 + qrow) * 2;
+                ml[0] = m_run;
+                ml[1] = l;
+            }
+            float* dst = a.part_o + ((size_t)split * a.M + r0 + qrow) * a.d + h * DK;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = o[db][4 * rr + r];
+                    *(f32x4*)(dst + db * 32 + 8 * rr + 4 * hi) = v;
+                }
+        }
+        return;
     }
     const float inv = 1.0f / l;
     if (qrow < len) {
@@ -913,6 +956,41 @@ __global__ __launch_bounds__(256) void attention_dump_kernel(const T* __restrict
     for (int k = lane; k < len; k += 64) out[k] = out[k] / sum;
 }
 
+// Merge of the key splits of attention32_kernel: ctx[m][c] = sum_s f_s O_s[m][c] / sum_s f_s l_s with f_s = exp2(m_s - max m)
+// over the splits that saw keys (l_s > 0; every row has at least one).  One lane per (row, four channels).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                T* __restrict__ ctx, int M, int d, int dk, int ldo, int ksplit) {
+    const int dv = d >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)M * dv) return;
+    const int m = (int)(idx / dv), c = (int)(idx % dv) * 4, h = c / dk, H = d / dk;
+    float ms[8], ls[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) {
+        ms[sp] = -INFINITY; ls[sp] = 0.f;
+        if (sp < ksplit) {
+            const float* ml = part_ml + (((size_t)sp * H + h) * M + m) * 2;
+            ms[sp] = ml[0]; ls[sp] = ml[1];
+            if (ls[sp] > 0.f) mx = fmaxf(mx, ms[sp]);
+        }
+    }
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sp = 0; sp < 8; ++sp) {
+        if (sp < ksplit && ls[sp] > 0.f) {
+            const float f = __builtin_amdgcn_exp2f(ms[sp] - mx);
+            L += ls[sp] * f;
+            const f32x4 o = *(const f32x4*)(part_o + ((size_t)sp * M + m) * d + c);
+            acc += o * f;
+        }
+    }
+    const float inv = 1.0f / L;
+    store4<T>(ctx + (size_t)m * ldo + c, acc * inv);
+}
+
 template <typename T, int DK, typename OT = T>
 static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStream_t stream) {
     constexpr int QT = sizeof(T) == 2 ? 2 : 1;     // 32 (bf16) / 16 (f32) queries per wave
@@ -930,6 +1008,27 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
             // config 4 B = 1, 86 -> 71 us; 264 or 448 workgroups are 10 % faster with one group, two per CU)
             const long items = (long)B * H * ((max_len + 127) / 128);
             const long items64 = (long)B * H * ((max_len + 63) / 64);
+            if (aa.ksplit > 1) {
+                // keys split over ksplit workgroups per work item (fs2_attention_ksplit): the four-group form while it
+                // stands on the chip one workgroup per CU, else the plain form; then the merge
+                const bool four_s = max_len > 4 * AT_BK && items64 * aa.ksplit <= 256;
+                static unsigned long long oks[2] = {0, 0};
+                const void* ks_k = four_s ? (const void*)attention32_kernel<DK, false, 4, 2, 1> : (const void*)attention32_kernel<DK, false, 1>;
+                const int lds_s = four_s ? 4 * (lds / 2) : lds;
+                fs2_allow_lds(ks_k, lds_s, &oks[four_s ? 1 : 0]);
+                const int nblk = four_s ? (max_len + 63) / 64 : (max_len + 127) / 128;
+                const dim3 grid_s = fs2_pair_order_grid(aa.order, nblk * aa.ksplit, H, B, xcd_on != 0);
+                void* params[] = {&aa};
+                if (hipLaunchKernel(ks_k, grid_s, dim3(four_s ? 512 : AT_THREADS), params, lds_s, stream) != hipSuccess) {
+                    fs2_set_error("fs2_attention: launch failed: %s", hipGetErrorString(hipGetLastError()));
+                    return FS2_ERR_HIP;
+                }
+                const long long n4 = (long long)aa.M * (aa.d / 4);
+                hipLaunchKernelGGL(attention_combine_kernel<bf16_t>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                                   aa.part_o, aa.part_ml, (bf16_t*)aa.ctx, aa.M, aa.d, DK, aa.ldo, aa.ksplit);
+                FS2_CHECK_LAUNCH("fs2_attention(combine)");
+                return FS2_OK;
+            }
             // four key groups (64-query workgroups) while those still stand on the chip one per CU: a single utterance
             const bool four = groups ? groups == 4 : (max_len > 4 * AT_BK && items64 <= 256 && !aa.drop.thresh);
             if (four) {
@@ -1009,7 +1108,8 @@ static int launch_attention_split(const AttnArgs& a, int B, int H, int max_len, 
 using namespace fs2;
 
 static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu, int B, int max_len, int M, int n_heads,
-                           int dk, int ld, int ldo, int dtype, Dropout drop, hipStream_t stream) {
+                           int dk, int ld, int ldo, int dtype, Dropout drop, hipStream_t stream, int ksplit = 1,
+                           float* workspace = nullptr) {
     FS2_CHECK_ARG(qkv && ctx && cu && B > 0 && n_heads > 0, "fs2_attention: bad args");
     FS2_CHECK_ARG(dtype == 0 || dtype == 1 || dtype == 2 || dtype == 3, "fs2_attention: dtype=%d", dtype);
     FS2_CHECK_ARG(dtype != 3 || ((dk == 64 || dk == 128) && ld % 32 == 0 && ((uintptr_t)qkv & 127) == 0),
@@ -1027,6 +1127,14 @@ static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu
     if (max_len <= 0) return FS2_OK;
     AttnArgs a;
     a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M; a.drop = drop;
+    a.ksplit = 1; a.part_o = nullptr; a.part_ml = nullptr;
+    if (ksplit > 1) {
+        FS2_CHECK_ARG(dtype == 1 && !lse && !drop.thresh && ksplit <= 8 && workspace && M > 0 && ((uintptr_t)workspace & 15) == 0,
+                      "fs2_attention_keysplit: bf16 inference only, ksplit <= 8, workspace and the total row count required");
+        a.ksplit = ksplit;
+        a.part_o = workspace;
+        a.part_ml = workspace + (size_t)ksplit * M * d;
+    }
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)dk);
 #define FS2_ATT(TT, DKK) return launch_attention<TT, DKK>(a, B, n_heads, max_len, stream)
     if (dtype == 3) {          // q | k | v and context in split-fp16 storage, fp16 matrix pipe
@@ -1056,6 +1164,45 @@ extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, i
                              int ldo, int dtype, hipStream_t stream) {
     return attention_entry(qkv, ctx, nullptr, cu, B, max_len, 0, n_heads, dk, ld, ldo, dtype, fs2_make_dropout(0, 0, 0.f),
                            stream);
+}
+
+// Split of the key range over several workgroups per (utterance, head, query block) for launches that leave CUs without
+// a workgroup: one long utterance (BASELINE config 4, B = 1).  1 = no split.  bf16 only.
+// Measured (tools/bench_attention.py, us per launch incl. the merge; unsplit -> split): one utterance of 1600 frames
+// 23.8 -> 19.6 (3 splits), 3138 frames 40.4 -> 31.3 (2), 4165 frames 51.9 -> 41.3 (3).  The split pays only until every
+// CU has ONE workgroup: a tile trip of this kernel runs as fast with one wave per SIMD as with two (4 x 4165 frames, 264
+// workgroups: 121.9 us unsplit, 117 / 109 us with 528 / 792 workgroups), and below four trips per key group the fixed
+// costs eat it (810 frames: 16.1 -> 15.8).  A batch (config 2) fills the chip with work items as it is.
+extern "C" int fs2_attention_ksplit(int B, int max_len, int n_heads, int dk, int dtype) {
+    if (dtype != 1 || B <= 0 || max_len <= 256 || !(dk == 32 || dk == 64 || dk == 96 || dk == 128)) return 1;
+    const long items64 = (long)B * n_heads * ((max_len + 63) / 64), items128 = (long)B * n_heads * ((max_len + 127) / 128);
+    if (items64 <= 128) {                         // four-group form (64 queries): >= 4 trips of 32 keys per group
+        long ks = 256 / items64;
+        const long by_len = ((max_len + 31) / 32) / 16;
+        ks = ks < by_len ? ks : by_len;
+        return (int)(ks < 1 ? 1 : (ks > 8 ? 8 : ks));
+    }
+    if (max_len >= 1024) {                        // plain form (128 queries, 64-key tiles)
+        long ks = 256 / items128;
+        const long by_len = ((max_len + 63) / 64) / 8;
+        ks = ks < by_len ? ks : by_len;
+        ks = ks > 8 ? 8 : ks;
+        if (ks >= 3) return (int)ks;              // (two splits: the two-group form of the unsplit launch does the same)
+    }
+    return 1;
+}
+
+extern "C" long long fs2_attention_keysplit_workspace(int M, int n_heads, int dk, int ksplit) {
+    return (long long)ksplit * M * ((long long)n_heads * dk + 2LL * n_heads) * (long long)sizeof(float);
+}
+
+// fs2_attention with the keys of every work item split over `ksplit` workgroups (fs2_attention_ksplit) and merged by a
+// second kernel; workspace: fs2_attention_keysplit_workspace bytes; M = total rows (cu[B]).  ksplit = 1: fs2_attention.
+extern "C" int fs2_attention_keysplit(const void* qkv, void* ctx, const int* cu, int B, int max_len, int M, int n_heads, int dk,
+                                      int ld, int ldo, int dtype, int ksplit, float* workspace, hipStream_t stream) {
+    FS2_CHECK_ARG(ksplit >= 1 && ksplit <= 8, "fs2_attention_keysplit: ksplit=%d (1..8)", ksplit);
+    return attention_entry(qkv, ctx, nullptr, cu, B, max_len, M, n_heads, dk, ld, ldo, dtype, fs2_make_dropout(0, 0, 0.f),
+                           stream, ksplit, workspace);
 }
 
 // Training forward: as fs2_attention, and saves lse[h][m] (log2 domain, M = total rows) for fs2_attention_bwd.

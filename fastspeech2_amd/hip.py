@@ -42,6 +42,7 @@ _SIGNATURES = {
     "fs2_proj_add_layernorm": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "fs2_add_layernorm": [_P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "fs2_sum_act_layernorm": [_P, _I, _L, _I, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "fs2_attention_keysplit": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "fs2_attention": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "fs2_attention_dump": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "fs2_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -85,12 +86,14 @@ _SIZE_QUERIES = {
     "fs2_colreduce_workspace": [_I, _I, _I],
     "fs2_colreduce_static_max_bytes": [],
     "fs2_bn_workspace": [_I, _I],
+    "fs2_attention_keysplit_workspace": [_I, _I, _I, _I],
 }
 # plain int queries (no launch, cannot fail)
 _INT_QUERIES = {
     "fs2_colreduce_static_init": [],
     "fs2_conv_gemm_ksplit": [_I, _I, _I, _I, _I],
     "fs2_conv_gemm_ksplit_act": [_I, _I, _I, _I, _I, _F],
+    "fs2_attention_ksplit": [_I, _I, _I, _I, _I],
     "fs2_conv_gemm256_plan": [_I, _I, _I, _I, _I, _I],
     "fs2_gemm_regw_plan": [_I, _I, _I, _I, _I, _I, _I],
     "fs2_proj_add_layernorm_plan": [_I, _I, _I, _I],

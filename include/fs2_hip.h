@@ -176,6 +176,16 @@ int fs2_sum_act_layernorm(const float* parts, int nparts, long long part_stride,
 int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, int max_len, int n_heads, int dk, int ld,
                   int ldo, int dtype, hipStream_t stream);
 
+/* fs2_attention for launches that would leave the chip to a few long serial chains (one long utterance, a handful of
+ * them: BASELINE config 4): the keys of every (utterance, head, query block) are split over `ksplit` workgroups, each
+ * leaves its unnormalised context and (max, sum) in `workspace`, a second kernel merges them (same softmax,
+ * network/encoder.py:78-88; fp32 merge).  bf16 (dtype 1) only.  fs2_attention_ksplit: the factor to use (1 = call
+ * fs2_attention; no launch); fs2_attention_keysplit_workspace: bytes of `workspace` (16-byte aligned); M = cu[B]. */
+int fs2_attention_ksplit(int B, int max_len, int n_heads, int dk, int dtype);
+long long fs2_attention_keysplit_workspace(int M, int n_heads, int dk, int ksplit);
+int fs2_attention_keysplit(const void* qkv, void* ctx, const int* cu, int B, int max_len, int M, int n_heads, int dk, int ld,
+                           int ldo, int dtype, int ksplit, float* workspace, hipStream_t stream);
+
 /* Debug: materialise softmax(QK^T/sqrt(dk)) of one utterance (rows row0..row0+len) as fp32
  * atten[n_heads][len][len] — what MultiHeadedAttention.atten holds (network/encoder.py:82-84),
  * consumed by calculate_all_attentions (network/fastspeech2.py:305-341). */

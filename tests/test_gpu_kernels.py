@@ -714,6 +714,58 @@ def test_attention(dtype, h, dk, lens):
     assert (att.cpu() - a).abs().max().item() <= 1e-4
 
 
+def test_attention_ksplit_rule():
+    ks = hip.load().fs2_attention_ksplit
+    assert ks(32, 945, 2, 128, 1) == 1            # the bench batch fills the chip as it is
+    assert ks(1, 810, 2, 128, 1) == 1             # config 1: two trips per key group, nothing to gain
+    assert ks(1, 3138, 2, 128, 1) == 2            # config 4, one utterance: 98 workgroups -> 196
+    assert ks(1, 4165, 2, 128, 1) == 3
+    assert ks(4, 4165, 2, 128, 1) == 1            # four of them: every CU has a workgroup already
+    assert ks(1, 120, 2, 128, 1) == 1 and ks(1, 3138, 2, 128, 0) == 1 and ks(1, 3138, 2, 128, 2) == 1
+    for B, T in [(1, 300), (1, 810), (2, 4165), (3, 2000), (8, 1500), (1, 20000)]:
+        k = ks(B, T, 2, 128, 1)
+        assert 1 <= k <= 8
+
+
+@pytest.mark.parametrize("h,dk,lens,ksplit", [(2, 128, [810], 3), (2, 128, [3138], 2), (2, 128, [4165, 4100, 130, 3900], 2),
+                                              (2, 64, [700, 31, 1, 300], 4), (4, 32, [1500, 64], 8), (4, 96, [333, 2000], 2),
+                                              (2, 128, [257], 8)])
+def test_attention_keysplit_equals_the_unsplit_launch(h, dk, lens, ksplit):
+    """fs2_attention_keysplit (keys of a work item over several workgroups + merge kernel) against fs2_attention on the
+    same bf16 inputs: same softmax, partial results merged in fp32 - equal up to one bf16 step of the context - and
+    against the fp64 reference at the bf16 bar of test_attention.  Short utterances
+    leave some splits without keys."""
+    d = h * dk
+    g = torch.Generator().manual_seed(sum(lens) + ksplit)
+    M = sum(lens)
+    qkv = (torch.randn(M, 3 * d, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device=DEV)
+    ctx0 = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ctx1 = torch.full((M, d), float("nan"), device=DEV, dtype=torch.bfloat16)
+    call("fs2_attention", ptr(qkv), ptr(ctx0), ptr(cu), len(lens), max(lens), h, dk, 3 * d, d, hip.BF16, stream())
+    nbytes = hip.load().fs2_attention_keysplit_workspace(M, h, dk, ksplit)
+    ws = torch.full((nbytes // 4,), float("nan"), device=DEV)
+    call("fs2_attention_keysplit", ptr(qkv), ptr(ctx1), ptr(cu), len(lens), max(lens), M, h, dk, 3 * d, d, hip.BF16, ksplit,
+         ptr(ws), stream())
+    a, b = ctx0.float(), ctx1.float()
+    assert torch.isfinite(b).all()
+    big = max(1.0, a.abs().max().item())
+    # (the probabilities are rounded to bf16 against different running maxima: many values land on the neighbouring bf16)
+    assert (a - b).abs().max().item() <= 2 ** -7 * big
+    # fp64 reference on the first and last utterance
+    q = qkv.float().cpu().double()
+    r0 = 0
+    for i, L in enumerate(lens):
+        if i in (0, len(lens) - 1):
+            for hh in range(h):
+                qq = q[r0:r0 + L, hh * dk:(hh + 1) * dk]
+                kk = q[r0:r0 + L, d + hh * dk:d + (hh + 1) * dk]
+                vv = q[r0:r0 + L, 2 * d + hh * dk:2 * d + (hh + 1) * dk]
+                ref = torch.softmax(qq @ kk.t() / math.sqrt(dk), -1) @ vv
+                assert (b[r0:r0 + L, hh * dk:(hh + 1) * dk].cpu().double() - ref).abs().max().item() <= 1.5e-2 * max(1.0, ref.abs().max().item())
+        r0 += L
+
+
 def test_embed_and_variance_add():
     g = torch.Generator().manual_seed(3)
     d, idim, M = 64, 30, 50

@@ -32,4 +32,15 @@ for dtype in (sys.argv[1:] or ["bf16", "fp32"]):
             call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu), len(lens), max(lens), h, dk, 3 * d, d, code, stream())
         med, mn = timeit(fn)
         fl = 4.0 * d * sum(float(n) * n for n in lens)
-        print("%-5s %-18s M=%6d  %8.1f us (min %8.1f)  %7.1f TFLOP/s" % (dtype, name, M, med, mn, fl / med / 1e6), flush=True)
+        extra = ""
+        ks = hip.load().fs2_attention_ksplit(len(lens), max(lens), h, dk, code)
+        forced = int(os.environ.get("FS2_BENCH_KSPLIT", "0"))
+        if (ks > 1 or forced > 1) and code == hip.BF16:      # what the engine launches for this shape: keys split + merge
+            ks = forced if forced > 1 else ks
+            ws = torch.empty(hip.load().fs2_attention_keysplit_workspace(M, h, dk, ks) // 4, device=DEV)
+            def fn2():
+                call("fs2_attention_keysplit", ptr(qkv), ptr(ctx), ptr(cu), len(lens), max(lens), M, h, dk, 3 * d, d, code, ks,
+                     ptr(ws), stream())
+            m2, _ = timeit(fn2)
+            extra = "   keys over %d workgroups + merge: %8.1f us" % (ks, m2)
+        print("%-5s %-18s M=%6d  %8.1f us (min %8.1f)  %7.1f TFLOP/s%s" % (dtype, name, M, med, mn, fl / med / 1e6, extra), flush=True)
