@@ -742,6 +742,9 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_split_kernel(AttnArgs
 
     int b, h, qblk;
     if (!fs2_pair_order_decode(a.order, b, h, qblk)) return;
+    // key split across workgroups (as attention32_kernel): block index = qblk * ksplit + split
+    const int ksplit = a.ksplit, split = qblk % ksplit;
+    qblk /= ksplit;
     const int r0 = a.cu[b];
     const int len = a.cu[b + 1] - r0;
     if (qblk * BQ >= len) return;
@@ -749,6 +752,19 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_split_kernel(AttnArgs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
+    const int ntiles_all = (len + BK - 1) / BK;
+    const int per_split = (ntiles_all + ksplit - 1) / ksplit;
+    const int s0 = split * per_split;
+    const int s1 = (s0 + per_split) < ntiles_all ? (s0 + per_split) : ntiles_all;
+    if (s0 >= s1) {       // this split has no keys: the merge must see l = 0
+        const int qr = qblk * BQ + wave * 16 + i;
+        if (g == 0 && qr < len) {
+            float* ml = a.part_ml + (((size_t)split * (a.d / DK) + h) * a.M + r0 + qr) * 2;
+            ml[0] = -INFINITY;
+            ml[1] = 0.f;
+        }
+        return;
+    }
     const unsigned ldb = (unsigned)a.ld * 4u;
     const unsigned char* __restrict__ base = (const unsigned char*)a.qkv + (size_t)r0 * ldb;
     const unsigned qcolb = (unsigned)(h * DK) * 4u, kcolb = (unsigned)(a.d + h * DK) * 4u, vcolb = (unsigned)(2 * a.d + h * DK) * 4u;
@@ -800,12 +816,11 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_split_kernel(AttnArgs
     const int vrow = 4 * g + (i >> 2);
     const int vx = vrow * ROWB + ((((i & 3) >> 1) ^ (2 * (vrow & 7))) << 4) + (i & 1) * 8;
 
-    const int ntiles = (len + BK - 1) / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < ntiles; ++kt) {
+    stage(s0, 0);
+    for (int kt = s0; kt < s1; ++kt) {
         vm_wait_barrier<0>();   // tile kt landed (explicit vmcnt(0)) + barrier: every wave is done with the other stage
-        if (kt + 1 < ntiles) stage(kt + 1, (kt + 1) & 1);
-        const unsigned char* Ks = smem + (kt & 1) * 2 * TILE_BYTES;
+        if (kt + 1 < s1) stage(kt + 1, (kt + 1 - s0) & 1);
+        const unsigned char* Ks = smem + ((kt - s0) & 1) * 2 * TILE_BYTES;
         const unsigned vs = (unsigned)(size_t)(at_lds_void*)(Ks + TILE_BYTES);
         const int k0 = kt * BK;
 
@@ -909,6 +924,19 @@ __global__ __launch_bounds__(AT_THREADS, 2) void attention_split_kernel(AttnArgs
     }
 
     float l = rows_sum(l_part);
+    if (ksplit > 1) {     // partial result of this key range (the context still carries AT_PSCALE: the merge divides it out)
+        if (qrow < len) {
+            if (g == 0) {
+                float* ml = a.part_ml + (((size_t)split * (a.d / DK) + h) * a.M + r0 + qrow) * 2;
+                ml[0] = m_run;
+                ml[1] = l;
+            }
+            float* dst = a.part_o + ((size_t)split * a.M + r0 + qrow) * a.d + h * DK;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) *(f32x4*)(dst + dt * 16 + 4 * g) = o[dt];
+        }
+        return;
+    }
     const float inv = 1.0f / (l * AT_PSCALE);
     if (qrow < len) {
         f16pair_t* dst = (f16pair_t*)a.ctx + (size_t)(r0 + qrow) * a.ldo + h * DK;
@@ -960,7 +988,8 @@ __global__ __launch_bounds__(256) void attention_dump_kernel(const T* __restrict
 // over the splits that saw keys (l_s > 0; every row has at least one).  One lane per (row, four channels).
 template <typename T>
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                                T* __restrict__ ctx, int M, int d, int dk, int ldo, int ksplit) {
+                                                                T* __restrict__ ctx, int M, int d, int dk, int ldo, int ksplit,
+                                                                float oscale) {
     const int dv = d >> 2;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)M * dv) return;
@@ -987,8 +1016,11 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
             acc += o * f;
         }
     }
-    const float inv = 1.0f / L;
-    store4<T>(ctx + (size_t)m * ldo + c, acc * inv);
+    const float inv = oscale / L;          // oscale: 1, or 1 / AT_PSCALE for the split-fp16 kernel's scaled probabilities
+    f32x4 v = acc * inv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v[r]));      // the rounded product is what gets stored / split
+    store4<T>(ctx + (size_t)m * ldo + c, v);
 }
 
 template <typename T, int DK, typename OT = T>
@@ -1025,7 +1057,7 @@ static int launch_attention(const AttnArgs& a, int B, int H, int max_len, hipStr
                 }
                 const long long n4 = (long long)aa.M * (aa.d / 4);
                 hipLaunchKernelGGL(attention_combine_kernel<bf16_t>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
-                                   aa.part_o, aa.part_ml, (bf16_t*)aa.ctx, aa.M, aa.d, DK, aa.ldo, aa.ksplit);
+                                   aa.part_o, aa.part_ml, (bf16_t*)aa.ctx, aa.M, aa.d, DK, aa.ldo, aa.ksplit, 1.0f);
                 FS2_CHECK_LAUNCH("fs2_attention(combine)");
                 return FS2_OK;
             }
@@ -1085,10 +1117,11 @@ static int launch_attention_split(const AttnArgs& a, int B, int H, int max_len, 
     // trips of the serial chain (us per launch, 32 / 64 keys: 1 x 120 phones 8.9 / 8.2, 1 x 512 22.7 / 20.2, 4 x 512
     // 23.2 / 20.8; batches: 32 x ~120 11.2 / 11.5, 128 x ~120 25.2 / 30.2)
     static const int bk_env = FS2_ENV_INT("FS2_ATTN_SPLIT_BK", 0);
-    const int bk = bk_env ? bk_env : ((long)B * H * ((max_len + 63) / 64) <= 128 ? 64 : 32);
+    const int bk = bk_env ? bk_env : ((long)B * H * ((max_len + 63) / 64) * a.ksplit <= 128 ? 64 : 32);
     static const int xcd_on = FS2_ENV_INT("FS2_ATTN_XCD", 1);
     AttnArgs aa = a;
-    const dim3 grid = fs2_pair_order_grid(aa.order, (max_len + 63) / 64, H, B, xcd_on != 0);
+    // (with a key split the grid carries ksplit x the query blocks and attention_combine_kernel follows)
+    const dim3 grid = fs2_pair_order_grid(aa.order, ((max_len + 63) / 64) * aa.ksplit, H, B, xcd_on != 0);
     static unsigned long long ok64 = 0, ok32 = 0;
     if (bk == 64) {
         constexpr int lds = 2 * 2 * 64 * DK * 4;
@@ -1100,6 +1133,12 @@ static int launch_attention_split(const AttnArgs& a, int B, int H, int max_len, 
         hipLaunchKernelGGL((attention_split_kernel<DK, 32>), grid, dim3(AT_THREADS), lds, stream, aa);
     }
     FS2_CHECK_LAUNCH("fs2_attention");
+    if (aa.ksplit > 1) {
+        const long long n4 = (long long)aa.M * (aa.d / 4);
+        hipLaunchKernelGGL(attention_combine_kernel<f16pair_t>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream,
+                           aa.part_o, aa.part_ml, (f16pair_t*)aa.ctx, aa.M, aa.d, DK, aa.ldo, aa.ksplit, 1.0f / AT_PSCALE);
+        FS2_CHECK_LAUNCH("fs2_attention(combine)");
+    }
     return FS2_OK;
 }
 
@@ -1129,8 +1168,10 @@ static int attention_entry(const void* qkv, void* ctx, float* lse, const int* cu
     a.qkv = qkv; a.ctx = ctx; a.cu = cu; a.ld = ld; a.ldo = ldo; a.d = d; a.lse = lse; a.M = M; a.drop = drop;
     a.ksplit = 1; a.part_o = nullptr; a.part_ml = nullptr;
     if (ksplit > 1) {
-        FS2_CHECK_ARG(dtype == 1 && !lse && !drop.thresh && ksplit <= 8 && workspace && M > 0 && ((uintptr_t)workspace & 15) == 0,
-                      "fs2_attention_keysplit: bf16 inference only, ksplit <= 8, workspace and the total row count required");
+        FS2_CHECK_ARG((dtype == 1 || dtype == 3) && !lse && !drop.thresh && ksplit <= 8 && workspace && M > 0 &&
+                          ((uintptr_t)workspace & 15) == 0,
+                      "fs2_attention_keysplit: bf16 / split-fp16 (dtype 1 / 3) inference only, ksplit <= 8, workspace and the "
+                      "total row count required");
         a.ksplit = ksplit;
         a.part_o = workspace;
         a.part_ml = workspace + (size_t)ksplit * M * d;
@@ -1167,15 +1208,23 @@ extern "C" int fs2_attention(const void* qkv, void* ctx, const int* cu, int B, i
 }
 
 // Split of the key range over several workgroups per (utterance, head, query block) for launches that leave CUs without
-// a workgroup: one long utterance (BASELINE config 4, B = 1).  1 = no split.  bf16 only.
+// a workgroup: one long utterance (BASELINE config 4, B = 1).  1 = no split.  bf16 (dtype 1) and the split-fp16 kernel
+// (dtype 3: one utterance of 512 phones 20.2 us unsplit).
 // Measured (tools/bench_attention.py, us per launch incl. the merge; unsplit -> split): one utterance of 1600 frames
 // 23.8 -> 19.6 (3 splits), 3138 frames 40.4 -> 31.3 (2), 4165 frames 51.9 -> 41.3 (3).  The split pays only until every
 // CU has ONE workgroup: a tile trip of this kernel runs as fast with one wave per SIMD as with two (4 x 4165 frames, 264
 // workgroups: 121.9 us unsplit, 117 / 109 us with 528 / 792 workgroups), and below four trips per key group the fixed
 // costs eat it (810 frames: 16.1 -> 15.8).  A batch (config 2) fills the chip with work items as it is.
 extern "C" int fs2_attention_ksplit(int B, int max_len, int n_heads, int dk, int dtype) {
-    if (dtype != 1 || B <= 0 || max_len <= 256 || !(dk == 32 || dk == 64 || dk == 96 || dk == 128)) return 1;
     const long items64 = (long)B * n_heads * ((max_len + 63) / 64), items128 = (long)B * n_heads * ((max_len + 127) / 128);
+    if (dtype == 3) {     // split-fp16 kernel (64 queries per workgroup, no key groups): >= 2 trips of 64 keys per split
+        if (B <= 0 || max_len <= 128 || !(dk == 64 || dk == 128) || items64 > 128) return 1;
+        long ks = 256 / items64;
+        const long by_len = ((max_len + 63) / 64) / 2;
+        ks = ks < by_len ? ks : by_len;
+        return (int)(ks < 1 ? 1 : (ks > 8 ? 8 : ks));
+    }
+    if (dtype != 1 || B <= 0 || max_len <= 256 || !(dk == 32 || dk == 64 || dk == 96 || dk == 128)) return 1;
     if (items64 <= 128) {                         // four-group form (64 queries): >= 4 trips of 32 keys per group
         long ks = 256 / items64;
         const long by_len = ((max_len + 31) / 32) / 16;

@@ -426,13 +426,14 @@ class Engine:
             prof = self.profile is not None and lens is not None
             with self._timed("attention:" + ("f16x3" if split_qkv else ("fp32" if ac == F32 else "bf16")) if prof else None, "flop",
                              4.0 * d * sum(float(n) * n for n in lens) if prof else 0.0):
-                aks = self._plan("fs2_attention_ksplit", int(B), int(max_len), int(self.h), int(dk), int(code)) \
-                    if (code == hip.BF16 and self.latency_split) else 1
+                acode = hip.F16X3_QKV if split_qkv else code
+                aks = self._plan("fs2_attention_ksplit", int(B), int(max_len), int(self.h), int(dk), int(acode)) \
+                    if self.latency_split else 1
                 if aks > 1:      # one long utterance / a handful: keys split over several workgroups per work item + merge
                     ws = self._empty((self._plan("fs2_attention_keysplit_workspace", int(M), int(self.h), int(dk), aks) // 4,),
                                      dtype=torch.float32)
                     call("fs2_attention_keysplit", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, M, self.h, dk, 3 * da, da,
-                         code, aks, ptr(ws), stream())
+                         acode, aks, ptr(ws), stream())
                 else:
                     call("fs2_attention", ptr(qkv), ptr(ctx), ptr(cu_dev), B, max_len, self.h, dk, 3 * da, da,
                          hip.F16X3_QKV if split_qkv else code, stream())

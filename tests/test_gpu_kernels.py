@@ -722,6 +722,7 @@ def test_attention_ksplit_rule():
     assert ks(1, 4165, 2, 128, 1) == 3
     assert ks(4, 4165, 2, 128, 1) == 1            # four of them: every CU has a workgroup already
     assert ks(1, 120, 2, 128, 1) == 1 and ks(1, 3138, 2, 128, 0) == 1 and ks(1, 3138, 2, 128, 2) == 1
+    assert ks(1, 512, 2, 128, 3) == 4 and ks(1, 120, 2, 128, 3) == 1 and ks(32, 150, 2, 128, 3) == 1      # split-fp16 kernel
     for B, T in [(1, 300), (1, 810), (2, 4165), (3, 2000), (8, 1500), (1, 20000)]:
         k = ks(B, T, 2, 128, 1)
         assert 1 <= k <= 8
@@ -764,6 +765,34 @@ def test_attention_keysplit_equals_the_unsplit_launch(h, dk, lens, ksplit):
                 ref = torch.softmax(qq @ kk.t() / math.sqrt(dk), -1) @ vv
                 assert (b[r0:r0 + L, hh * dk:(hh + 1) * dk].cpu().double() - ref).abs().max().item() <= 1.5e-2 * max(1.0, ref.abs().max().item())
         r0 += L
+
+
+@pytest.mark.parametrize("h,dk,lens,ksplit", [(2, 128, [512], 4), (2, 128, [810], 6), (2, 64, [300, 77, 1, 129], 3),
+                                              (2, 128, [3138], 2), (4, 64, [130], 8)])
+def test_split_fp16_attention_keysplit_equals_the_unsplit_launch(h, dk, lens, ksplit):
+    """fs2_attention_keysplit on split-fp16 q | k | v (dtype 3) against fs2_attention on the same operands: the partial
+    results are merged in fp32, so the two agree to fp32 summation noise (and the context comes back in split-fp16
+    storage: hi + lo)."""
+    d = h * dk
+    g = torch.Generator().manual_seed(sum(lens) * 7 + ksplit)
+    M = sum(lens)
+    q32 = (torch.randn(M, 3 * d, generator=g) * 1.5).to(DEV)
+    qs = torch.empty_like(q32)
+    call("fs2_cast", ptr(q32), ptr(qs), M * 3 * d, hip.F16X3, stream())
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device=DEV)
+    ctx0 = torch.full((M, d), float("nan"), device=DEV)
+    ctx1 = torch.full((M, d), float("nan"), device=DEV)
+    call("fs2_attention", ptr(qs), ptr(ctx0), ptr(cu), len(lens), max(lens), h, dk, 3 * d, d, hip.F16X3_QKV, stream())
+    ws = torch.full((hip.load().fs2_attention_keysplit_workspace(M, h, dk, ksplit) // 4,), float("nan"), device=DEV)
+    call("fs2_attention_keysplit", ptr(qs), ptr(ctx1), ptr(cu), len(lens), max(lens), M, h, dk, 3 * d, d, hip.F16X3_QKV,
+         ksplit, ptr(ws), stream())
+
+    def joined(t):
+        hh = t.cpu().view(torch.float16).view(M, d // 32, 2, 32).float()
+        return (hh[:, :, 0] + hh[:, :, 1]).reshape(M, d)
+    a, b = joined(ctx0), joined(ctx1)
+    assert torch.isfinite(b).all()
+    assert (a - b).abs().max().item() <= 4e-6 * max(1.0, a.abs().max().item())
 
 
 def test_embed_and_variance_add():
