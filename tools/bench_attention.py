@@ -18,6 +18,9 @@ cases = [("bench.py batch", np.load(_fix)["frames"].astype(int).tolist()),     #
          ("config 1 B=1", [810]), ("one of 1600", [1600]), ("config 4 B=1 (512 ph)", [3138]),
          ("config 4 B=1", [4165]), ("config 4 B=4", [4165, 4100, 3900, 4000]),
          ("uniform 64 x 1024", [1024] * 64)]      # no imbalance: the tile code's own rate
+only = os.environ.get("FS2_BENCH_CASE", "")       # substring: run this case alone (PMC passes: tools/attn_pmc.sh)
+if only:
+    cases = [c for c in cases if only in c[0]]
 order = os.environ.get("FS2_BENCH_SORT", "")      # "desc" / "asc": utterances sorted by length (decode() hands over descending)
 if order:
     cases = [(n, sorted(l, reverse=order == "desc")) for n, l in cases]
