@@ -143,9 +143,10 @@ def require_gpu() -> torch.device:
 
 
 def ptr(t):
+    """device address of a tensor as a plain int (ctypes converts it for a `void*` parameter; None = NULL)"""
     if t is None:
         return None
-    return c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 try:                                   # fast path: two C calls instead of torch.cuda.current_stream()'s Python layers,
@@ -156,13 +157,19 @@ except AttributeError:                 # pragma: no cover - other torch builds
 
 
 def stream():
-    """hipStream_t of torch's current stream on the current device"""
+    """hipStream_t of torch's current stream on the current device (as an int; 0 = the null stream)"""
     if _raw_stream is not None:
-        return c_void_p(_raw_stream(_cur_device()))
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(_cur_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
+_fn = {}       # entry points by name (one dict lookup per launch instead of load() + getattr on the CDLL)
 
 
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    fn = _fn.get(name)
+    if fn is None:
+        fn = _fn[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
         raise HipError("%s failed (%d): %s" % (name, rc, load().fs2_last_error().decode()))

@@ -293,7 +293,7 @@ class TrainEngine:
     def _ws(self, nbytes, raw_stream=None):
         """Kernel scratch (split partials, per-workgroup sums).  One buffer per stream, grown on demand: the kernels
         that use it run in order on that stream, each done with it before the next one starts."""
-        key = stream().value if raw_stream is None else raw_stream
+        key = stream() if raw_stream is None else raw_stream
         n = (max(int(nbytes), 16) + 3) // 4
         buf = self._ws_cache.get(key)
         if buf is None or buf.numel() < n:
