@@ -285,7 +285,7 @@ def test_f16x3_everywhere_is_fp32_grade_on_the_bench_batch():
         assert np.abs(res["f16x3"]["mel"][cu[b]:cu[b + 1]] - o["mel"].numpy()).max() <= FP32_MEL_TOL
 
 
-@pytest.mark.parametrize("n_phones", [120, 37, 450])
+@pytest.mark.parametrize("n_phones", [120, 37, 450, (200, 33, 7)])
 def test_single_utterance_latency_schedule_equals_the_batch_schedule(n_phones):
     """BASELINE config 1 (one utterance): with a few hundred tokens the engine runs the ReLU convs split-K and applies
     the ReLU to the summed partials (Engine.latency_split, fs2_conv_gemm_ksplit_act / fs2_sum_act_layernorm).  Same
@@ -294,7 +294,11 @@ def test_single_utterance_latency_schedule_equals_the_batch_schedule(n_phones):
     from fastspeech2_amd import synth
     kw = dict(synth.BASELINE_OVERRIDES)
     sd = synth.bench_state_dict()
-    ids = torch.from_numpy(np.random.Generator(np.random.PCG64(n_phones)).integers(1, synth.BENCH_IDIM, size=n_phones))
+    lens = n_phones if isinstance(n_phones, tuple) else (n_phones,)        # (a small ragged batch takes the same schedule)
+    n_phones = sum(lens)
+    rng = np.random.Generator(np.random.PCG64(n_phones))
+    utts = [torch.from_numpy(rng.integers(1, synth.BENCH_IDIM, size=n)) for n in lens]
+    ids = utts[0]
     model = FeedForwardTransformer(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.eval().cuda().set_precision("bf16", "f16x3")
@@ -305,18 +309,19 @@ def test_single_utterance_latency_schedule_equals_the_batch_schedule(n_phones):
     res = {}
     for on in (True, False):
         eng.latency_split = on
-        pk = model.infer_batch([ids])["packed"]
+        pk = model.infer_batch(utts)["packed"]
         res[on] = (pk["durations_pred"].cpu().numpy(), pk["log_durations"].cpu().numpy(), pk["mel"].float().cpu().numpy())
     eng.latency_split = True
     assert np.array_equal(res[True][0], res[False][0])
     assert np.abs(res[True][1] - res[False][1]).max() <= 5e-6
     assert res[True][2].shape == res[False][2].shape
     cfg = fs2_oracle.full_cfg(synth.BENCH_IDIM, synth.BENCH_ODIM, use_scaled_pos_enc=True, **kw)
-    o = fs2_oracle.infer_one({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, ids)
-    assert np.array_equal(res[True][0], o["durations"].numpy())
-    assert np.abs(res[True][1] - o["log_durations"].numpy()).max() <= 5e-6
+    o = fs2_oracle.infer_one({k: torch.from_numpy(v) for k, v in sd.items()}, cfg, ids)      # first utterance
+    n0, t0 = lens[0], int(o["mel"].shape[0])
+    assert np.array_equal(res[True][0][:n0], o["durations"].numpy())
+    assert np.abs(res[True][1][:n0] - o["log_durations"].numpy()).max() <= 5e-6
     for on in (True, False):
-        assert np.abs(res[on][2] - o["mel"].numpy()).max() <= BF16_MEL_TOL, on
+        assert np.abs(res[on][2][:t0] - o["mel"].numpy()).max() <= BF16_MEL_TOL, on
 
 
 @pytest.mark.parametrize("variant", ["small_ln_outputs", "large_ffn_hidden"])
