@@ -67,7 +67,7 @@ BATCH = 32
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)      # the pipelined loop pays one fill + drain (~1.5 ms) per timed run: DESIGN.md 5.1
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "f16x3"],
                     help="frame-level half; f16x3 = fp32-grade results on error-compensated fp16 operand pairs (3 MFMAs per product)")
